@@ -1,0 +1,113 @@
+"""Seeded synthetic panoramas, depth maps and Sim(2) hypotheses.
+
+There is no dataset on the GPU box, so tests, golden vectors and ``bench.py`` all
+draw their inputs from here.  Everything is plain numpy and deterministic for a
+given (pano index, H, W) / (seed, N, P).
+
+* depth: ray-cast of an axis-aligned box room seen from the origin, in the
+  HoHoNet pano frame (-x towards the pano centre column, see
+  ``hohonet_pano_utils.get_uni_sphere_xyz``), quantised to uint16 millimetres
+  -- the on-disk ``.depth.png`` format of the reference
+  (reference: salve/utils/infer_depth.py:55-62, read back at
+  salve/utils/bev_rendering_utils.py:367).
+* rgb: uint8 [H, W, 3]; smooth sinusoids + uniform noise.  Even pano indices are
+  clamped to >= 1 in every channel, odd ones are unrestricted so that colours
+  whose uint8 channel product wraps to zero occur (the mask rule of
+  salve/utils/interpolation_utils.py:95-98).
+* hypotheses: theta ~ U[0, 360) deg, t ~ U[-2, 2]^2, s = 1, stored as float32
+  like ``Sim2`` does (reference: salve/common/sim2.py:50-52).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Tuple
+
+import numpy as np
+
+from salve_amd.utils.hohonet_pano_utils import get_uni_sphere_xyz
+
+FLOOR_Z = -1.5
+CEILING_Z = 1.2
+WALL_X = (-2.5, 3.0)
+WALL_Y = (-2.0, 3.5)
+WALL_JITTER = 0.5
+
+
+def make_box_room_depth_mm(pano_idx: int, H: int = 512, W: int = 1024) -> np.ndarray:
+    """uint16 [H, W] depth in millimetres of a jittered box room."""
+    rng = np.random.default_rng(seed=pano_idx)
+    jit = rng.uniform(-WALL_JITTER, WALL_JITTER, size=4)
+    x0, x1 = WALL_X[0] + jit[0], WALL_X[1] + jit[1]
+    y0, y1 = WALL_Y[0] + jit[2], WALL_Y[1] + jit[3]
+    d = get_uni_sphere_xyz(H, W)  # unit directions [H, W, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tx = np.where(d[..., 0] > 0, x1 / d[..., 0], np.where(d[..., 0] < 0, x0 / d[..., 0], np.inf))
+        ty = np.where(d[..., 1] > 0, y1 / d[..., 1], np.where(d[..., 1] < 0, y0 / d[..., 1], np.inf))
+        tz = np.where(d[..., 2] > 0, CEILING_Z / d[..., 2], np.where(d[..., 2] < 0, FLOOR_Z / d[..., 2], np.inf))
+    t = np.minimum(np.minimum(tx, ty), tz)
+    mm = np.round(t * 1000.0)
+    return np.clip(mm, 0, 65535).astype(np.uint16)
+
+
+def make_pano_rgb(pano_idx: int, H: int = 512, W: int = 1024) -> np.ndarray:
+    """uint8 [H, W, 3] synthetic panorama texture."""
+    rng = np.random.default_rng(seed=1_000_003 + pano_idx)
+    v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    ph = rng.uniform(0, 2 * np.pi, size=6)
+    fr = rng.uniform(3.0, 11.0, size=6)
+    chans = []
+    for c in range(3):
+        base = 127.5 + 90.0 * np.sin(2 * np.pi * fr[2 * c] * u / W + ph[2 * c]) * np.cos(
+            2 * np.pi * fr[2 * c + 1] * v / H + ph[2 * c + 1]
+        )
+        chans.append(base)
+    img = np.stack(chans, axis=-1) + rng.uniform(-37.0, 37.0, size=(H, W, 3))
+    img = np.clip(np.round(img), 0, 255).astype(np.uint8)
+    if pano_idx % 2 == 0:
+        img = np.maximum(img, 1)
+    return img
+
+
+def make_pano(pano_idx: int, H: int = 512, W: int = 1024) -> Tuple[np.ndarray, np.ndarray]:
+    """(rgb uint8 [H,W,3], depth uint16 [H,W])."""
+    return make_pano_rgb(pano_idx, H, W), make_box_room_depth_mm(pano_idx, H, W)
+
+
+@dataclass
+class HypothesisTable:
+    """N alignment hypotheses i2Ti1 over P panoramas (structure of arrays)."""
+
+    i1: np.ndarray  # int32 [N] pano rendered under the pose
+    i2: np.ndarray  # int32 [N] pano rendered at identity
+    R: np.ndarray  # float32 [N, 2, 2]
+    t: np.ndarray  # float32 [N, 2]
+    theta_deg: np.ndarray  # float64 [N]
+
+    def __len__(self) -> int:
+        return int(self.i1.shape[0])
+
+    def shard(self, rank: int, world: int) -> "HypothesisTable":
+        """Contiguous block split, rank r gets rows [r*N/G, (r+1)*N/G)."""
+        n = len(self)
+        lo = (rank * n) // world
+        hi = ((rank + 1) * n) // world
+        return HypothesisTable(self.i1[lo:hi], self.i2[lo:hi], self.R[lo:hi], self.t[lo:hi], self.theta_deg[lo:hi])
+
+
+def make_hypotheses(n: int, num_panos: int, seed: int = 0) -> HypothesisTable:
+    rng = np.random.default_rng(seed)
+    theta = rng.uniform(0.0, 360.0, size=n)
+    t = rng.uniform(-2.0, 2.0, size=(n, 2))
+    i1 = rng.integers(0, num_panos, size=n)
+    if num_panos > 1:
+        off = rng.integers(1, num_panos, size=n)
+        i2 = (i1 + off) % num_panos
+    else:
+        i2 = i1.copy()
+    th = np.deg2rad(theta)
+    c, s = np.cos(th), np.sin(th)
+    R = np.stack([np.stack([c, -s], -1), np.stack([s, c], -1)], -2)
+    return HypothesisTable(
+        i1.astype(np.int32), i2.astype(np.int32), R.astype(np.float32), t.astype(np.float32), theta
+    )
