@@ -1,0 +1,132 @@
+/*
+ * salve_hip.h -- C ABI of libsalve_hip.so, the MI355X (gfx950) implementation of SALVe's hot path:
+ * the per-hypothesis BEV texture-map rasteriser and the early-fusion ResNet verifier.
+ *
+ * The reference (zillow/salve @ 2024_10_08) is pure Python and has NO FFI for this path; the boundary it
+ * exposes is a set of Python call sites.  Each entry point below names the reference interface it stands
+ * behind (paths relative to the reference tree).  The Python facade in salve_amd/ binds these symbols with
+ * ctypes and reproduces the reference's signatures, None-returns and exceptions.
+ *
+ * Conventions
+ *   - Every pointer marked "device" is a raw HIP device pointer owned by the caller (PyTorch on the host
+ *     side); the library never allocates per call and never frees caller memory.
+ *   - All work is enqueued on the given hipStream_t (passed as void*; NULL = the null stream) and is
+ *     asynchronous with respect to the host.
+ *   - Return value: 0 = OK, negative = salve_status_t; salve_last_error() gives a thread-local message.
+ *     No C++ exception crosses this boundary.
+ *   - One host thread + one process per GPU is the supported model; handles are not thread-safe.
+ */
+#ifndef SALVE_HIP_H
+#define SALVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SALVE_OK = 0,
+    SALVE_ERR_BAD_ARG = -1,
+    SALVE_ERR_UNSUPPORTED = -2,
+    SALVE_ERR_HIP = -3,
+    SALVE_ERR_WORKSPACE = -4
+} salve_status_t;
+
+#define SALVE_HIP_ABI_VERSION 1
+
+/* Library / ABI version (SALVE_HIP_ABI_VERSION). */
+int salve_hip_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* salve_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * BEV rasteriser.
+ * Stands behind salve/utils/bev_rendering_utils.py: get_xyzrgb_from_depth (:347-414), the pose
+ * application of render_bev_pair (:443-451), render_bev_image (:254-328) and, underneath it,
+ * zorder_utils.choose_elevated_repeated_vals (salve/utils/zorder_utils.py:10-83),
+ * interpolation_utils.interp_dense_grid_from_sparse / remove_hallucinated_content
+ * (salve/utils/interpolation_utils.py:21-54, 74-122).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* The constants the reference hard-codes, gathered in one struct. */
+typedef struct {
+    int32_t pano_h, pano_w;     /* working pano resolution: 512 x 1024 (bev_rendering_utils.py:373-374) */
+    int32_t crop_rows;          /* int(pano_h * crop_ratio) rows dropped top and bottom (:397-401); 80 */
+    int32_t bev_h, bev_w;       /* BEVParams.img_h + 1, img_w + 1 (:292-293); 501, 501 */
+    int32_t mask_k;             /* box-filter size of remove_hallucinated_content; 11 */
+    float depth_scale;          /* uint16 depth -> metres, applied in float32 (:367); 0.001f */
+    int32_t reserved0;
+    double win_xmin, win_xmax, win_ymin, win_ymax; /* prune_to_2d_bbox window, inclusive (:38-45); -5, 5, -5, 5 */
+    double img_tx, img_ty, img_scale; /* bevimg_Sim2_world: (p + t) * s (bevparams.py:69-78); 5, 5, 50 */
+    double rot_pre[4];          /* rotmat2d(-90), row-major float64 exactly as numpy computes it (:443) */
+    double z_lo[2], z_hi[2];    /* crop_z_range per surface id (lo < z <= hi) (:560-566): floor, ceiling */
+    double z_min;               /* z-order slicing: slices of 1 unit on [z_min, z_min + n_slices) */
+    int32_t n_slices;           /* (zorder_utils.py:11: zmin -2, zmax 2, 4 slices) */
+    int32_t reserved1;
+} salve_bev_config_t;
+
+/* One render = one panorama surface under one Sim(2) pose (a row of the reference's work list,
+ * scripts/render_dataset_bev.py:91-109). R, t are Sim2's float32 storage (salve/common/sim2.py:50-51). */
+typedef struct {
+    int32_t pano_idx;   /* which panorama of the batch */
+    int32_t surface;    /* 0 = floor, 1 = ceiling */
+    float R[4];         /* i2Ti1.rotation, row-major */
+    float t[2];         /* i2Ti1.translation (the x1.5 HoHoNet->ZInD factor is applied by the kernel, :448-451) */
+    int32_t apply_pose; /* 1: pano-1 of the pair (pose applied), 0: pano-2 (identity) */
+    int32_t reserved;
+} salve_bev_hyp_t;
+
+/* Bytes of device workspace salve_bev_render_batch needs for n renders (0 on bad config). */
+size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n);
+
+/*
+ * Render n BEV texture maps.
+ *   pano_rgb    device uint8  [P, pano_h, pano_w, 3]
+ *   pano_depth  device uint16 [P, pano_h, pano_w]          (.depth.png payload, millimetres)
+ *   sphere      device double [2*pano_h + 2*pano_w]: r[v], zdir[v], cos(theta_u), sin(theta_u), computed on the
+ *               host exactly as hohonet_pano_utils.get_uni_sphere_xyz does (salve/utils/hohonet_pano_utils.py:27-43)
+ *   hyps        device salve_bev_hyp_t [n]
+ *   out_bev     device uint32 [n, bev_h, bev_w]: final BEV image (after mask and np.flipud), 0x00BBGGRR
+ *   dbg_img_xy  device int16 [n, (pano_h-2*crop_rows)*pano_w, 2] or NULL: BEV pixel (x, y) of every pano point,
+ *               (-1, -1) if the point is cropped / pruned (row a4: the bit-exact index contract)
+ *   dbg_keys    device uint64 [n, bev_h*bev_w] or NULL: z-order winner per pixel (unflipped):
+ *               0 = empty, else ((slice+1) << 45) | (point_index << 24) | 0xBBGGRR
+ *   dbg_mask    device uint8 [n, bev_h, bev_w] or NULL: hallucination mask (unflipped)
+ *   dbg_stats   device int32 [n, 8] or NULL: {n_sites, wrap_steps, error_flag, ...}
+ */
+int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth,
+                           int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n,
+                           uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
+                           int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* BEV uint32 -> uint8 [n, bev_h, bev_w, 3], the array render_bev_image returns (bev_rendering_utils.py:328). */
+int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream);
+
+/*
+ * Verifier input tiles: Resize (cv2 INTER_LINEAR, uint8 fixed point) -> centre Crop -> ToTensor -> Normalize,
+ * i.e. salve/train_utils.py:126-159 with salve/utils/transform.py:256-272, 386-420, 105-123, 177-202.
+ *   jobs        device salve_tile_job_t [n_jobs]
+ *   coef_y/x    device int32 [resize, 4]: {src0, src1, w0, w1} 11-bit taps per resized row / column
+ *   lut         device float [3, 256]: (v - mean_c) / std_c evaluated in float32 on the host
+ *   out         SALVE_TILE_F32_NCHW : float [slots, out_c, crop, crop]
+ *               SALVE_TILE_BF16_NHWC: bf16  [slots, crop, crop, out_c]
+ */
+typedef struct {
+    int64_t bev_offset; /* element offset of the source image inside `bev` (uint32 units) */
+    int32_t slot;       /* destination sample */
+    int32_t chan;       /* first of the 3 destination channels */
+} salve_tile_job_t;
+
+#define SALVE_TILE_F32_NCHW 0
+#define SALVE_TILE_BF16_NHWC 1
+
+int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs, int32_t n_jobs,
+                    const int32_t* coef_y, const int32_t* coef_x, int32_t resize, int32_t crop, const float* lut,
+                    void* out, int32_t out_format, int32_t out_c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SALVE_HIP_H */

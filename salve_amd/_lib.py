@@ -1,0 +1,106 @@
+"""ctypes binding of libsalve_hip.so (C ABI: include/salve_hip.h).
+
+The product path has NO fallback: if the HIP library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"`) every entry point raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "libsalve_hip.so"
+
+SALVE_OK = 0
+TILE_F32_NCHW = 0
+TILE_BF16_NHWC = 1
+
+# every symbol include/salve_hip.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = (
+    "salve_hip_version",
+    "salve_last_error",
+    "salve_bev_workspace_bytes",
+    "salve_bev_render_batch",
+    "salve_bev_export_u8",
+    "salve_bev_tiles",
+    "salve_resnet_create",
+    "salve_resnet_destroy",
+    "salve_resnet_workspace_bytes",
+    "salve_resnet_forward",
+    "salve_resnet_num_layers",
+)
+
+
+class BevConfig(ctypes.Structure):
+    """salve_bev_config_t"""
+
+    _fields_ = [
+        ("pano_h", ctypes.c_int32), ("pano_w", ctypes.c_int32), ("crop_rows", ctypes.c_int32),
+        ("bev_h", ctypes.c_int32), ("bev_w", ctypes.c_int32), ("mask_k", ctypes.c_int32),
+        ("depth_scale", ctypes.c_float), ("reserved0", ctypes.c_int32),
+        ("win_xmin", ctypes.c_double), ("win_xmax", ctypes.c_double),
+        ("win_ymin", ctypes.c_double), ("win_ymax", ctypes.c_double),
+        ("img_tx", ctypes.c_double), ("img_ty", ctypes.c_double), ("img_scale", ctypes.c_double),
+        ("rot_pre", ctypes.c_double * 4),
+        ("z_lo", ctypes.c_double * 2), ("z_hi", ctypes.c_double * 2),
+        ("z_min", ctypes.c_double), ("n_slices", ctypes.c_int32), ("reserved1", ctypes.c_int32),
+    ]
+
+
+HYP_DTYPE = np.dtype(
+    [("pano_idx", "<i4"), ("surface", "<i4"), ("R", "<f4", (4,)), ("t", "<f4", (2,)), ("apply_pose", "<i4"),
+     ("reserved", "<i4")]
+)
+TILE_JOB_DTYPE = np.dtype([("bev_offset", "<i8"), ("slot", "<i4"), ("chan", "<i4")])
+assert HYP_DTYPE.itemsize == 40 and TILE_JOB_DTYPE.itemsize == 16
+
+_lib = None
+
+
+class SalveHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library or raise -- never substitute a CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise SalveHipError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run __graft_entry__.build() "
+            "(hipcc --offload-arch=gfx950). salve_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(str(LIB_PATH))
+    vp, i32, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_size_t
+    lib.salve_hip_version.restype = ctypes.c_int
+    lib.salve_last_error.restype = ctypes.c_char_p
+    lib.salve_bev_workspace_bytes.argtypes = [ctypes.POINTER(BevConfig), i32]
+    lib.salve_bev_workspace_bytes.restype = sz
+    lib.salve_bev_render_batch.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.salve_bev_render_batch.restype = ctypes.c_int
+    lib.salve_bev_export_u8.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.salve_bev_export_u8.restype = ctypes.c_int
+    lib.salve_bev_tiles.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
+    lib.salve_bev_tiles.restype = ctypes.c_int
+    if hasattr(lib, "salve_resnet_create"):
+        lib.salve_resnet_create.argtypes = [i32, i32, i32, i32, vp, ctypes.c_int64, vp]
+        lib.salve_resnet_create.restype = vp
+        lib.salve_resnet_destroy.argtypes = [vp]
+        lib.salve_resnet_destroy.restype = None
+        lib.salve_resnet_workspace_bytes.argtypes = [vp, i32]
+        lib.salve_resnet_workspace_bytes.restype = sz
+        lib.salve_resnet_forward.argtypes = [vp, vp, i32, vp, vp, sz, vp]
+        lib.salve_resnet_forward.restype = ctypes.c_int
+        lib.salve_resnet_num_layers.argtypes = [vp]
+        lib.salve_resnet_num_layers.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != SALVE_OK:
+        msg = load().salve_last_error().decode("utf-8", "replace")
+        raise SalveHipError(f"{what} failed with status {status}: {msg}")

@@ -1,0 +1,517 @@
+// bev_render.hip -- BEV texture-map rasteriser for gfx950 (MI355X).  Compile with -ffp-contract=off.
+//
+// One render = one panorama surface under one Sim(2) pose -> one 501x501 BEV image.  Three kernels:
+//
+//   bev_scatter_kernel   (HBM-streaming)  pano RGB u8 + depth u16 -> back-project, pose, prune, round to BEV pixel,
+//                        z-order splat by 64-bit atomicMax into an L2-resident key image [bev_h*bev_w] u64.
+//                        Reference: bev_rendering_utils.py:367-413 (back-projection), :443-451 (pose),
+//                        :274-287 (prune + pixel index), zorder_utils.py:10-83 (winner), :307-308 (sparse image).
+//   bev_densify_kernel   (LDS/VALU)  one workgroup per render: occupancy + "non-empty" bitmaps in LDS (2 x 32 KB),
+//                        11x11 dilation mask on the bitmaps, then every site walks its own Delaunay star
+//                        (star_delaunay.h) and rasterises the triangles it owns with exact rational barycentric
+//                        weights.  Reference: interpolation_utils.py:21-54 (griddata linear), :74-122 (mask),
+//                        bev_rendering_utils.py:318-319 (mask multiply, flipud).
+//   bev_tile_kernel      BEV -> verifier input tile (resize 234, crop 224, normalise).  Reference:
+//                        train_utils.py:126-159, transform.py:256-272, 386-420, 105-123, 177-202.
+//
+// Exactness: pixel indices follow the reference's float64 op order bit for bit (float32 depth product, float64
+// table products, the FMA order of numpy's BLAS matmul, half-to-even rounding); everything after the pixel index
+// is integer arithmetic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/salve_hip.h"
+#include "star_delaunay.h"
+#include "salve_common.h"
+
+namespace {
+
+constexpr int SCATTER_THREADS = 256;
+constexpr int PTS_PER_THREAD = 4;
+constexpr int DENSIFY_THREADS = 512;
+constexpr int MASK_ROWS_PER_TASK = 16;
+constexpr int MASK_MAX_HALF = 8;
+
+struct DevCfg {
+    int pano_h, pano_w, crop_rows, rows, npts;
+    int H, W, wpr, mask_half;
+    float depth_scale;
+    double xmin, xmax, ymin, ymax, tx, ty, scale;
+    double rp00, rp01, rp10, rp11;
+    double zlo[2], zhi[2], zmin;
+    int nslices;
+};
+
+// ------------------------------------------------------------------------------------------------ scatter
+__global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
+    DevCfg c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, const double* __restrict__ sphere,
+    const salve_bev_hyp_t* __restrict__ hyps, unsigned long long* __restrict__ keys, int16_t* __restrict__ dbg_xy) {
+    const int rid = blockIdx.y;
+    const salve_bev_hyp_t h = hyps[rid];
+    const int p0 = (blockIdx.x * SCATTER_THREADS + threadIdx.x) * PTS_PER_THREAD;  // first point (cropped raster)
+    if (p0 >= c.npts) return;
+    const int v = p0 / c.pano_w + c.crop_rows;
+    const int u0 = p0 % c.pano_w;  // pano_w is a multiple of 4: the four points share the row
+    const size_t pix = ((size_t)h.pano_idx * c.pano_h + v) * c.pano_w + u0;
+
+    const double* rr = sphere;
+    const double* zd = sphere + c.pano_h;
+    const double* ct = sphere + 2 * c.pano_h;
+    const double* st = ct + c.pano_w;
+    const double rv = rr[v], zv = zd[v];
+
+    const uint2 dq = *reinterpret_cast<const uint2*>(depth + pix);  // 4 x u16
+    const uint32_t* rgbw = reinterpret_cast<const uint32_t*>(rgb + pix * 3);
+    const uint32_t w0 = rgbw[0], w1 = rgbw[1], w2 = rgbw[2];  // 12 bytes = 4 pixels
+    const uint32_t col[4] = {w0 & 0xFFFFFFu, (w0 >> 24) | ((w1 & 0xFFFFu) << 8), (w1 >> 16) | ((w2 & 0xFFu) << 16),
+                             w2 >> 8};
+    const uint32_t dep[4] = {dq.x & 0xFFFFu, dq.x >> 16, dq.y & 0xFFFFu, dq.y >> 16};
+
+    const double zlo = c.zlo[h.surface], zhi = c.zhi[h.surface];
+    const double R00 = (double)h.R[0], R01 = (double)h.R[1], R10 = (double)h.R[2], R11 = (double)h.R[3];
+    const double tx = (double)(h.t[0] * 1.5f), ty = (double)(h.t[1] * 1.5f);  // float32 product, then widened
+    unsigned long long* kimg = keys + (size_t)rid * c.H * c.W;
+
+#pragma unroll
+    for (int k = 0; k < PTS_PER_THREAD; k++) {
+        const int u = u0 + k;
+        const float d32 = (float)dep[k] * c.depth_scale;
+        const double d = (double)d32;
+        const double z = d * zv;
+        int ix = -1, iy = -1;
+        if (z > zlo && z <= zhi) {
+            const double x = d * (rv * ct[u]);
+            const double y = d * (rv * st[u]);
+            // xy @ rotmat2d(-90).T, evaluated like OpenBLAS' FMA dgemm kernel: fma(y, R01, x*R00)
+            double x1 = fma(y, c.rp01, x * c.rp00);
+            double y1 = fma(y, c.rp11, x * c.rp10);
+            if (h.apply_pose) {
+                const double x2 = fma(y1, R01, x1 * R00) + tx;
+                const double y2 = fma(y1, R11, x1 * R10) + ty;
+                x1 = x2;
+                y1 = y2;
+            }
+            if (c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax) {
+                // bevimg_Sim2_world.transform_from: (p @ I.T + t) * s, then np.round (half to even)
+                const double fx = rint((fma(y1, 0.0, x1 * 1.0) + c.tx) * c.scale);
+                const double fy = rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
+                ix = (int)fx;
+                iy = (int)fy;
+                const double zs = floor(z) - c.zmin;  // unit slices from an integer z_min: exact
+                if (zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H) {
+                    const unsigned long long key = ((unsigned long long)((int)zs + 1) << 45) |
+                                                   ((unsigned long long)(p0 + k) << 24) | col[k];
+                    atomicMax(kimg + (size_t)iy * c.W + ix, key);
+                }
+            }
+        }
+        if (dbg_xy) {
+            int16_t* o = dbg_xy + ((size_t)rid * c.npts + p0 + k) * 2;
+            o[0] = (int16_t)ix;
+            o[1] = (int16_t)iy;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ densify
+struct RasterEmit {
+    int H, W, wpr;
+    const uint32_t* occ;
+    const uint32_t* msk;
+    const unsigned long long* keys;
+    uint32_t* bev;  // flipped output image of this render
+
+    __device__ __forceinline__ uint32_t blend(int32_t wa, int32_t wb, int32_t wc, int32_t area, uint32_t ca,
+                                              uint32_t cb, uint32_t cc) const {
+        uint32_t out = 0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const int64_t num = (int64_t)wa * ((ca >> (8 * ch)) & 255) + (int64_t)wb * ((cb >> (8 * ch)) & 255) +
+                                (int64_t)wc * ((cc >> (8 * ch)) & 255);
+            // floor of the exact rational; the double quotient cannot round across an integer (num < 2^53, area < 2^23)
+            const uint32_t q = (uint32_t)((double)num / (double)area);
+            out |= q << (8 * ch);
+        }
+        return out;
+    }
+
+    __device__ __forceinline__ void operator()(int ax, int ay, int bx, int by, int cx, int cy) const {
+        const int32_t area = sd_orient(ax, ay, bx, by, cx, cy);
+        if (area <= 0) return;
+        int x0 = min(ax, min(bx, cx)), x1 = max(ax, max(bx, cx));
+        const int y0 = min(ay, min(by, cy)), y1 = max(ay, max(by, cy));
+        uint32_t ca = 0, cb = 0, cc = 0;
+        bool have = false;
+        const bool wide = (x1 - x0) > 40;
+        for (int y = y0; y <= y1; y++) {
+            int xa = x0, xb = x1;
+            if (wide) {
+                // exact span of the triangle on this row: intersect the three half-planes E_i(x) = A_i x + D_i >= 0
+                const int ex[3][4] = {{bx, by, cx, cy}, {cx, cy, ax, ay}, {ax, ay, bx, by}};
+                bool empty = false;
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    const int px = ex[e][0], py = ex[e][1], qx = ex[e][2], qy = ex[e][3];
+                    const int32_t A = -(qy - py);
+                    const int32_t D = (qx - px) * (y - py) + (qy - py) * px;
+                    if (A > 0) {  // x >= ceil(-D / A)
+                        int32_t n = -D;
+                        int32_t q = n / A;
+                        if (n % A > 0) q++;
+                        xa = max(xa, q);
+                    } else if (A < 0) {  // x <= floor(D / -A)
+                        int32_t m = -A;
+                        int32_t q = D / m;
+                        if (D % m < 0) q--;
+                        xb = min(xb, q);
+                    } else if (D < 0) {
+                        empty = true;
+                    }
+                }
+                if (empty || xa > xb) continue;
+            }
+            for (int w = xa >> 5; w <= (xb >> 5); w++) {
+                uint32_t bits = msk[y * wpr + w] & ~occ[y * wpr + w];
+                const int lo = xa - (w << 5), hi = xb - (w << 5);
+                if (lo > 0) bits &= 0xFFFFFFFFu << lo;
+                if (hi < 31) bits &= 0xFFFFFFFFu >> (31 - hi);
+                while (bits) {
+                    const int x = (w << 5) + (__ffs((int)bits) - 1);
+                    bits &= bits - 1;
+                    const int32_t wa = sd_orient(bx, by, cx, cy, x, y);
+                    const int32_t wb = sd_orient(cx, cy, ax, ay, x, y);
+                    const int32_t wc = area - wa - wb;
+                    if ((wa | wb | wc) < 0) continue;
+                    if (!have) {
+                        ca = (uint32_t)keys[(size_t)ay * W + ax] & 0xFFFFFFu;
+                        cb = (uint32_t)keys[(size_t)by * W + bx] & 0xFFFFFFu;
+                        cc = (uint32_t)keys[(size_t)cy * W + cx] & 0xFFFFFFu;
+                        have = true;
+                    }
+                    bev[(size_t)(H - 1 - y) * W + x] = blend(wa, wb, wc, area, ca, cb, cc);
+                }
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ unsigned long long load_key(const unsigned long long* p) {
+    // keys were produced by L2 atomics of another kernel / by this workgroup's peers: read them past the L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
+    DevCfg c, const unsigned long long* __restrict__ keys_all, uint32_t* __restrict__ bev_all,
+    uint32_t* __restrict__ sitelist_all, uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int H = c.H, W = c.W, wpr = c.wpr;
+    uint32_t* occ = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* msk = occ + H * wpr;
+    int16_t* rmin = reinterpret_cast<int16_t*>(msk + H * wpr);
+    const int Hp = (H + 1) & ~1;  // keep the int32 scalars 4-byte aligned behind the two int16 arrays
+    int16_t* rmax = rmin + Hp;
+    int* scal = reinterpret_cast<int*>(rmax + Hp);  // [0] n_sites [1] min x [2] max x [3] rows [4] steps [5] err
+
+    const int rid = blockIdx.x;
+    const unsigned long long* keys = keys_all + (size_t)rid * H * W;
+    uint32_t* bev = bev_all + (size_t)rid * H * W;
+    uint32_t* sitelist = sitelist_all + (size_t)rid * H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = DENSIFY_THREADS >> 6;
+    const int p = c.mask_half;
+
+    if (tid < 8) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : 0);
+    __syncthreads();
+
+    // ---- phase B: bitmaps by wave ballot (no LDS atomics), row extents, compact site list.
+    //      `msk` receives the horizontally dilated "non-empty" bits (uint8 channel product wraps mod 256).
+    const int nseg = (W + 63) >> 6;
+    for (int y = wave; y < H; y += nwaves) {
+        int lo = W, hi = -1;
+        unsigned long long ne_prev = 0, ne_cur = 0;
+        for (int seg = 0; seg <= nseg; seg++) {
+            unsigned long long ob = 0, ne_next = 0;
+            if (seg < nseg) {
+                const int x = (seg << 6) + lane;
+                unsigned long long key = 0;
+                if (x < W) key = load_key(keys + (size_t)y * W + x);
+                const bool site = key != 0;
+                const uint32_t r = (uint32_t)key & 255u, gch = ((uint32_t)key >> 8) & 255u, b = ((uint32_t)key >> 16) & 255u;
+                const bool ne = site && (((r * gch * b) & 255u) != 0);
+                ob = __ballot(site);
+                ne_next = __ballot(ne);
+                if (ob) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&scal[0], __popcll(ob));
+                    base = __shfl(base, 0);
+                    if (site) sitelist[base + __popcll(ob & ((1ull << lane) - 1ull))] = ((uint32_t)y << 16) | (uint32_t)x;
+                    lo = min(lo, (seg << 6) + (int)__ffsll((long long)ob) - 1);
+                    hi = max(hi, (seg << 6) + 63 - (int)__clzll((long long)ob));
+                }
+                if (lane == 0) {
+                    occ[y * wpr + 2 * seg] = (uint32_t)ob;
+                    if (2 * seg + 1 < wpr) occ[y * wpr + 2 * seg + 1] = (uint32_t)(ob >> 32);
+                }
+            }
+            if (seg > 0) {  // emit the dilated bits of segment seg-1 (needs its two neighbours)
+                unsigned long long dil = ne_cur;
+                for (int d = 1; d <= p; d++) {
+                    dil |= (ne_cur << d) | (ne_prev >> (64 - d));
+                    dil |= (ne_cur >> d) | (ne_next << (64 - d));
+                }
+                if (lane == 0) {
+                    const int s = seg - 1;
+                    msk[y * wpr + 2 * s] = (uint32_t)dil;
+                    if (2 * s + 1 < wpr) msk[y * wpr + 2 * s + 1] = (uint32_t)(dil >> 32);
+                }
+            }
+            ne_prev = ne_cur;
+            ne_cur = ne_next;
+        }
+        if (lane == 0) {
+            rmin[y] = (int16_t)lo;
+            rmax[y] = (int16_t)hi;
+            if (hi >= 0) {
+                atomicMin(&scal[1], lo);
+                atomicMax(&scal[2], hi);
+                atomicAdd(&scal[3], 1);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: vertical dilation, in place.  A task = one bitmap column word x 16 rows; every task first
+    //      pulls its rows plus the halo into registers, then (after a barrier) stores the ORs.
+    {
+        const int ntask_rows = (H + MASK_ROWS_PER_TASK - 1) / MASK_ROWS_PER_TASK;
+        const int ntasks = ntask_rows * wpr;
+        // DENSIFY_THREADS >= ntasks is checked on the host
+        uint32_t rows[MASK_ROWS_PER_TASK + 2 * MASK_MAX_HALF];
+        const bool active = tid < ntasks;
+        const int w = tid % wpr, yb = (tid / wpr) * MASK_ROWS_PER_TASK;
+#pragma unroll
+        for (int i = 0; i < MASK_ROWS_PER_TASK + 2 * MASK_MAX_HALF; i++) {
+            const int y = yb - MASK_MAX_HALF + i;
+            rows[i] = (active && y >= 0 && y < H && i >= MASK_MAX_HALF - p && i < MASK_ROWS_PER_TASK + MASK_MAX_HALF + p)
+                          ? msk[y * wpr + w]
+                          : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MASK_ROWS_PER_TASK; i++) {
+            const int y = yb + i;
+            uint32_t v = 0;
+#pragma unroll
+            for (int d = -MASK_MAX_HALF; d <= MASK_MAX_HALF; d++)
+                if (d >= -p && d <= p) v |= rows[i + MASK_MAX_HALF + d];
+            if (active && y < H) msk[y * wpr + w] = v;
+        }
+    }
+    __syncthreads();
+
+    const int nsites = scal[0];
+    // interp_dense_grid_from_sparse early-outs (interpolation_utils.py:39-43): < 4 points, all x equal, all y equal
+    const bool degenerate = nsites < 4 || scal[1] == scal[2] || scal[3] <= 1;
+
+    // ---- phase D: base image = data pixels under the mask (at a data pixel the interpolant is the datum), 0 elsewhere.
+    for (int y = wave; y < H; y += nwaves) {
+        for (int seg = 0; seg < nseg; seg++) {
+            const int x = (seg << 6) + lane;
+            if (x >= W) continue;
+            const uint32_t ow = occ[y * wpr + (x >> 5)], mw = msk[y * wpr + (x >> 5)];
+            const bool m = (mw >> (x & 31)) & 1u;
+            uint32_t val = 0;
+            if (!degenerate && m && ((ow >> (x & 31)) & 1u)) val = (uint32_t)load_key(keys + (size_t)y * W + x) & 0xFFFFFFu;
+            bev[(size_t)(H - 1 - y) * W + x] = val;
+            if (dbg_mask) dbg_mask[((size_t)rid * H + y) * W + x] = m ? 1 : 0;
+        }
+    }
+    // the site list and the base image were written by this workgroup through L2: make them visible to all its waves
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+    // ---- phase E: Delaunay stars + rasterisation of owned triangles.
+    if (!degenerate) {
+        SdGrid g = {H, W, wpr, occ, rmin, rmax};
+        RasterEmit emit = {H, W, wpr, occ, msk, keys, bev};
+        int steps = 0, err = 0;
+        for (int i = tid; i < nsites; i += DENSIFY_THREADS) {
+            const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int r = sd_star(g, (int)(s & 0xFFFFu), (int)(s >> 16), emit);
+            if (r < 0) err = 1; else steps += r;
+        }
+        if (dbg_stats) {
+            atomicAdd(&scal[4], steps);
+            if (err) atomicOr(&scal[5], 1);
+        }
+    }
+    if (dbg_stats) {
+        __syncthreads();
+        if (tid < 8) dbg_stats[rid * 8 + tid] = tid < 6 ? scal[tid] : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ tiles
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (inputs are finite)
+    return (uint16_t)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void bev_tile_kernel(const uint32_t* __restrict__ bev, int W,
+                                                       const salve_tile_job_t* __restrict__ jobs,
+                                                       const int32_t* __restrict__ coef_y,
+                                                       const int32_t* __restrict__ coef_x, int resize, int crop,
+                                                       const float* __restrict__ lut, void* __restrict__ out, int fmt,
+                                                       int out_c) {
+    const salve_tile_job_t job = jobs[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= crop * crop) return;
+    const int i = idx / crop, j = idx % crop;
+    const int off = (resize - crop) / 2;
+    const int4 cy = reinterpret_cast<const int4*>(coef_y)[i + off];
+    const int4 cx = reinterpret_cast<const int4*>(coef_x)[j + off];
+    const uint32_t* img = bev + job.bev_offset;
+    const uint32_t p00 = img[(size_t)cy.x * W + cx.x], p01 = img[(size_t)cy.x * W + cx.y];
+    const uint32_t p10 = img[(size_t)cy.y * W + cx.x], p11 = img[(size_t)cy.y * W + cx.y];
+    float v[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const int a = (p00 >> (8 * ch)) & 255, b = (p01 >> (8 * ch)) & 255;
+        const int cc = (p10 >> (8 * ch)) & 255, d = (p11 >> (8 * ch)) & 255;
+        const int S0 = a * cx.z + b * cx.w;  // horizontal pass, x2048
+        const int S1 = cc * cx.z + d * cx.w;
+        int r = (((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2;
+        r = min(max(r, 0), 255);
+        v[ch] = lut[ch * 256 + r];
+    }
+    if (fmt == SALVE_TILE_F32_NCHW) {
+        float* o = reinterpret_cast<float*>(out) + ((size_t)job.slot * out_c + job.chan) * crop * crop + idx;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) o[(size_t)ch * crop * crop] = v[ch];
+    } else {
+        uint16_t* o = reinterpret_cast<uint16_t*>(out) + ((size_t)job.slot * crop * crop + idx) * out_c + job.chan;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) o[ch] = f32_to_bf16(v[ch]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bev_export_kernel(const uint32_t* __restrict__ bev, size_t npx,
+                                                         uint8_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npx) return;
+    const uint32_t v = bev[i];
+    out[3 * i] = (uint8_t)v;
+    out[3 * i + 1] = (uint8_t)(v >> 8);
+    out[3 * i + 2] = (uint8_t)(v >> 16);
+}
+
+bool make_devcfg(const salve_bev_config_t* cfg, DevCfg* d) {
+    if (!cfg) return salve_fail("null config");
+    if (cfg->pano_w <= 0 || cfg->pano_w % 4 != 0) return salve_fail("pano_w must be a positive multiple of 4");
+    if (cfg->pano_h <= 0 || cfg->crop_rows < 0 || 2 * cfg->crop_rows >= cfg->pano_h) return salve_fail("bad pano_h / crop_rows");
+    if (cfg->bev_h < 2 || cfg->bev_w < 2 || cfg->bev_h >= SD_MAX_DIM || cfg->bev_w >= SD_MAX_DIM) return salve_fail("bev size out of range");
+    if (cfg->mask_k < 1 || (cfg->mask_k & 1) == 0 || cfg->mask_k / 2 > MASK_MAX_HALF) return salve_fail("mask_k must be odd and <= 17");
+    if (cfg->n_slices < 1 || cfg->n_slices > 62) return salve_fail("n_slices out of range");
+    d->pano_h = cfg->pano_h; d->pano_w = cfg->pano_w; d->crop_rows = cfg->crop_rows;
+    d->rows = cfg->pano_h - 2 * cfg->crop_rows;
+    d->npts = d->rows * cfg->pano_w;
+    if ((long long)d->npts >= (1ll << 21)) return salve_fail("too many pano points for the 21-bit index field");
+    d->H = cfg->bev_h; d->W = cfg->bev_w; d->wpr = (cfg->bev_w + 31) / 32; d->mask_half = cfg->mask_k / 2;
+    d->depth_scale = cfg->depth_scale;
+    d->xmin = cfg->win_xmin; d->xmax = cfg->win_xmax; d->ymin = cfg->win_ymin; d->ymax = cfg->win_ymax;
+    d->tx = cfg->img_tx; d->ty = cfg->img_ty; d->scale = cfg->img_scale;
+    d->rp00 = cfg->rot_pre[0]; d->rp01 = cfg->rot_pre[1]; d->rp10 = cfg->rot_pre[2]; d->rp11 = cfg->rot_pre[3];
+    for (int i = 0; i < 2; i++) { d->zlo[i] = cfg->z_lo[i]; d->zhi[i] = cfg->z_hi[i]; }
+    d->zmin = cfg->z_min; d->nslices = cfg->n_slices;
+    const int ntasks = ((d->H + MASK_ROWS_PER_TASK - 1) / MASK_ROWS_PER_TASK) * d->wpr;
+    if (ntasks > DENSIFY_THREADS) return salve_fail("bev image too large for the LDS mask pass");
+    return true;
+}
+
+size_t densify_lds_bytes(const DevCfg& d) {
+    return (size_t)2 * d.H * d.wpr * 4 + (size_t)2 * ((d.H + 1) & ~1) * 2 + 64;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n) {
+    DevCfg d;
+    if (n <= 0 || !make_devcfg(cfg, &d)) return 0;
+    const size_t npx = (size_t)d.H * d.W;
+    return (size_t)n * npx * (sizeof(unsigned long long) + sizeof(uint32_t)) + 256;
+}
+
+int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth,
+                           int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n,
+                           uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
+                           int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream) {
+    DevCfg d;
+    if (!make_devcfg(cfg, &d)) return SALVE_ERR_BAD_ARG;
+    if (n == 0) return SALVE_OK;
+    if (n < 0 || n_panos <= 0 || !pano_rgb || !pano_depth || !sphere || !hyps || !out_bev || !workspace) {
+        salve_fail("salve_bev_render_batch: null pointer or bad count");
+        return SALVE_ERR_BAD_ARG;
+    }
+    if (n > 65535) { salve_fail("at most 65535 renders per call"); return SALVE_ERR_BAD_ARG; }
+    const size_t need = salve_bev_workspace_bytes(cfg, n);
+    if (workspace_bytes < need) { salve_fail("workspace too small"); return SALVE_ERR_WORKSPACE; }
+    const size_t lds = densify_lds_bytes(d);
+    if (lds > 160 * 1024) { salve_fail("bev image does not fit the 160 KB LDS"); return SALVE_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t npx = (size_t)d.H * d.W;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    uint32_t* sitelist = reinterpret_cast<uint32_t*>(keys + (size_t)n * npx);
+
+    SALVE_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)n * npx * sizeof(unsigned long long), s));
+    const int pts_per_block = SCATTER_THREADS * PTS_PER_THREAD;
+    dim3 g1((d.npts + pts_per_block - 1) / pts_per_block, n);
+    hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, keys,
+                       dbg_img_xy);
+    SALVE_HIP_CHECK(hipGetLastError());
+    static bool attr_set = false;
+    if (!attr_set) {
+        SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, keys, out_bev, sitelist, dbg_mask,
+                       dbg_stats);
+    SALVE_HIP_CHECK(hipGetLastError());
+    if (dbg_keys) SALVE_HIP_CHECK(hipMemcpyAsync(dbg_keys, keys, (size_t)n * npx * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    (void)n_panos;
+    return SALVE_OK;
+}
+
+int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream) {
+    if (n == 0) return SALVE_OK;
+    if (!bev || !out || n < 0 || bev_h <= 0 || bev_w <= 0) { salve_fail("salve_bev_export_u8: bad argument"); return SALVE_ERR_BAD_ARG; }
+    const size_t npx = (size_t)n * bev_h * bev_w;
+    hipLaunchKernelGGL(bev_export_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bev, npx, out);
+    SALVE_HIP_CHECK(hipGetLastError());
+    return SALVE_OK;
+}
+
+int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs, int32_t n_jobs,
+                    const int32_t* coef_y, const int32_t* coef_x, int32_t resize, int32_t crop, const float* lut,
+                    void* out, int32_t out_format, int32_t out_c, void* stream) {
+    if (n_jobs == 0) return SALVE_OK;
+    if (!bev || !jobs || !coef_y || !coef_x || !lut || !out || n_jobs < 0 || bev_h <= 0 || bev_w <= 0) {
+        salve_fail("salve_bev_tiles: null pointer or bad size");
+        return SALVE_ERR_BAD_ARG;
+    }
+    if (crop <= 0 || resize < crop || out_c < 3) { salve_fail("salve_bev_tiles: need 0 < crop <= resize, out_c >= 3"); return SALVE_ERR_BAD_ARG; }
+    if (out_format != SALVE_TILE_F32_NCHW && out_format != SALVE_TILE_BF16_NHWC) { salve_fail("unknown tile format"); return SALVE_ERR_UNSUPPORTED; }
+    if (n_jobs > 65535) { salve_fail("at most 65535 tile jobs per call"); return SALVE_ERR_BAD_ARG; }
+    dim3 g((crop * crop + 255) / 256, n_jobs);
+    hipLaunchKernelGGL(bev_tile_kernel, g, dim3(256), 0, (hipStream_t)stream, bev, bev_w, jobs, coef_y, coef_x, resize, crop,
+                       lut, out, out_format, out_c);
+    SALVE_HIP_CHECK(hipGetLastError());
+    return SALVE_OK;
+}
+
+}  // extern "C"

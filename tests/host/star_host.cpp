@@ -1,0 +1,39 @@
+// Host build of salve_amd/csrc/star_delaunay.h (the SAME source the HIP kernel compiles) so that the
+// star-wrapping algorithm can be unit-tested against the oracle without a GPU.  Test-only.
+#include <vector>
+#include <cstring>
+#include "../../salve_amd/csrc/star_delaunay.h"
+
+struct Collect {
+    std::vector<int>* out;
+    void operator()(int ax, int ay, int bx, int by, int cx, int cy) {
+        int v[6] = {ax, ay, bx, by, cx, cy};
+        out->insert(out->end(), v, v + 6);
+    }
+};
+
+extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H, int W, int* tri_xy, int cap,
+                                     long long* total_steps) {
+    int wpr = (W + 31) / 32;
+    std::vector<uint32_t> occ((size_t)H * wpr, 0);
+    std::vector<int16_t> rmin(H, (int16_t)W), rmax(H, (int16_t)-1);
+    for (int i = 0; i < n; i++) {
+        occ[(size_t)ys[i] * wpr + (xs[i] >> 5)] |= 1u << (xs[i] & 31);
+        if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
+        if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
+    }
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data()};
+    std::vector<int> out;
+    Collect c = {&out};
+    long long steps = 0;
+    for (int i = 0; i < n; i++) {
+        int s = sd_star(g, xs[i], ys[i], c);
+        if (s < 0) return -1;
+        steps += s;
+    }
+    if (total_steps) *total_steps = steps;
+    int nt = (int)(out.size() / 6);
+    if (nt > cap) return -2;
+    memcpy(tri_xy, out.data(), out.size() * sizeof(int));
+    return nt;
+}

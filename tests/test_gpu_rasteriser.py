@@ -1,0 +1,127 @@
+"""GPU parity of the HIP rasteriser against the CPU oracle (exact mode), through the C ABI."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import bev_oracle as bo  # noqa: E402
+from salve_amd import _lib, synthetic  # noqa: E402
+from salve_amd.rasteriser import BevRasteriser, pack_hypotheses  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def setup():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    dev = torch.device("cuda:0")
+    ras = BevRasteriser(dev)
+    panos = [synthetic.make_pano(i) for i in range(2)]
+    rgb = np.stack([p[0] for p in panos])
+    depth = np.stack([p[1] for p in panos])
+    d_rgb, d_depth = ras.upload_panos(rgb, depth)
+    hyp = synthetic.make_hypotheses(16, 2, seed=0)
+    return ras, panos, d_rgb, d_depth, hyp
+
+
+def oracle_render(panos, pano_idx, surface, R, t, apply_pose):
+    rgb, depth = panos[pano_idx]
+    zr = bo.floor_ceiling_z_range(surface)
+    xyzrgb, idx = bo.xyzrgb_from_arrays(depth, rgb, zr, return_index=True)
+    if apply_pose:
+        a, _ = bo.pose_pair(xyzrgb, xyzrgb[:1], R, t)
+    else:
+        _, a = bo.pose_pair(xyzrgb[:1], xyzrgb, R, t)
+    res = bo.render_bev_image(a, mode="exact")
+    return res, idx
+
+
+def unpack_keys(keys, H=501, W=501):
+    keys = keys.astype(np.uint64).reshape(H, W)
+    occupied = keys != 0
+    rgb = np.stack([(keys >> np.uint64(8 * c)) & np.uint64(255) for c in range(3)], -1).astype(np.uint8)
+    point = ((keys >> np.uint64(24)) & np.uint64((1 << 21) - 1)).astype(np.int64)
+    return occupied, rgb, point
+
+
+def test_render_matches_oracle_bit_for_bit(setup):
+    ras, panos, d_rgb, d_depth, hyp = setup
+    rows = []
+    for hi in range(4):
+        surface = "floor" if hi % 2 == 0 else "ceiling"
+        rows.append((int(hyp.i1[hi]), surface, hyp.R[hi], hyp.t[hi], 1))
+        rows.append((int(hyp.i2[hi]), surface, hyp.R[hi], hyp.t[hi], 0))
+    h = pack_hypotheses([r[0] for r in rows], [0 if r[1] == "floor" else 1 for r in rows], np.stack([r[2] for r in rows]),
+                        np.stack([r[3] for r in rows]), [r[4] for r in rows])
+    bev, dbg = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), len(rows), debug=True)
+    torch.cuda.synchronize()
+    bev_u8 = ras.export_u8(bev).cpu().numpy()
+    img_xy = dbg.img_xy.cpu().numpy()
+    keys = dbg.keys.cpu().numpy()
+    mask = dbg.mask.cpu().numpy()
+    stats = dbg.stats.cpu().numpy()
+    for k, (pi, surface, R, t, ap) in enumerate(rows):
+        res, idx = oracle_render(panos, pi, surface, R, t, ap)
+        # (a4) pixel index of every pano point, bit-exact; dropped points are (-1, -1)
+        exp_xy = np.full((ras.npts, 2), -1, dtype=np.int16)
+        exp_xy[idx[res["kept"]]] = res["img_xy"].astype(np.int16)
+        assert np.array_equal(img_xy[k], exp_xy), f"render {k}: pixel indices differ"
+        # (a5, a6) z-order winners and the sparse image
+        occupied, rgb, point = unpack_keys(keys[k])
+        win = idx[res["kept"]][res["valid"]]
+        wxy = res["img_xy"][res["valid"]]
+        exp_point = np.full((501, 501), -1, dtype=np.int64)
+        exp_point[wxy[:, 1], wxy[:, 0]] = win
+        assert np.array_equal(occupied, exp_point >= 0)
+        assert np.array_equal(point[occupied], exp_point[occupied])
+        assert np.array_equal(np.where(occupied[..., None], rgb, 0), res["sparse"])
+        # (a8) hallucination mask
+        assert np.array_equal(mask[k].astype(bool), res["mask"])
+        # (a7 + a8 + flipud) final image
+        assert stats[k, 5] == 0, "star walk hit its safety bound"
+        assert stats[k, 0] == int(res["valid"].sum())
+        diff = (bev_u8[k] != res["bev"]).any(-1)
+        assert diff.sum() == 0, f"render {k}: {diff.sum()} BEV pixels differ"
+
+
+def test_tiles_match_oracle(setup):
+    ras, panos, d_rgb, d_depth, hyp = setup
+    h = pack_hypotheses([0, 1], [0, 1], hyp.R[:2], hyp.t[:2], [1, 0])
+    bev, _ = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), 2)
+    out = torch.zeros((1, 6, 224, 224), dtype=torch.float32, device=ras.device)
+    jobs = ras.upload_tile_jobs([0, 1], [0, 0], [0, 3])
+    ras.tiles(bev, jobs, 2, out, _lib.TILE_F32_NCHW, 6)
+    out_bf = torch.zeros((1, 224, 224, 8), dtype=torch.bfloat16, device=ras.device)
+    ras.tiles(bev, jobs, 2, out_bf, _lib.TILE_BF16_NHWC, 8)
+    torch.cuda.synchronize()
+    bev_u8 = ras.export_u8(bev).cpu().numpy()
+    exp = np.concatenate([bo.tile_from_bev(bev_u8[0]), bo.tile_from_bev(bev_u8[1])], 0)
+    assert np.array_equal(out.cpu().numpy()[0], exp)  # integer taps + float32 LUT: exact
+    got_bf = out_bf.float().cpu().numpy()[0].transpose(2, 0, 1)
+    assert np.array_equal(got_bf[:6], torch.from_numpy(exp).bfloat16().float().numpy())
+    assert not got_bf[6:].any()
+
+
+def test_degenerate_inputs(setup):
+    """Empty window, < 4 sites: the reference returns None / zeros (bev_rendering_utils.py:279, interpolation_utils.py:39)."""
+    ras, panos, d_rgb, d_depth, hyp = setup
+    R = np.eye(2, dtype=np.float32)[None]
+    t = np.array([[40.0, 40.0]], dtype=np.float32)  # pushes every point out of the 10 m window
+    h = pack_hypotheses([0], [0], R, t, [1])
+    bev, dbg = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), 1, debug=True)
+    torch.cuda.synchronize()
+    assert int(dbg.stats[0, 0]) == 0
+    assert not bev.any()
+    assert (dbg.img_xy == -1).all()
+
+
+def test_bad_arguments_are_reported(setup):
+    ras, panos, d_rgb, d_depth, hyp = setup
+    import ctypes
+
+    st = ras.lib.salve_bev_render_batch(ctypes.byref(ras.cfg), None, None, 1, None, None, 1, None, None, None, None, None, None, 0, None)
+    assert st == -1 and b"null" in ras.lib.salve_last_error()
+    with pytest.raises(_lib.SalveHipError):
+        ras.tiles(torch.zeros(1, device=ras.device, dtype=torch.int32), ras.upload_tile_jobs([0], [0], [0]), 1,
+                  torch.zeros(1, device=ras.device), 7, 6)
