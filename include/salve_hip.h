@@ -126,6 +126,43 @@ int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const sal
                     const int32_t* coef_y, const int32_t* coef_x, int32_t resize, int32_t crop, const float* lut,
                     void* out, int32_t out_format, int32_t out_c, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Verifier: early-fusion ResNet forward pass (bf16 MFMA, fp32 accumulation).
+ * Stands behind salve/models/early_fusion.py:14-83 (EarlyFusionCEResnet), the torchvision trunk
+ * selected by salve/models/resnet_factory.py:26-44, and the model build / checkpoint load of
+ * salve/train_utils.py:205-242.  The host folds BatchNorm into the convolutions and describes the
+ * network as a list of ops over a few activation buffers; the library executes the list.
+ * ------------------------------------------------------------------------------------------------ */
+#define SALVE_OP_CONV 0       /* out = relu?(conv(in) + bias (+ res)) ; NHWC bf16 */
+#define SALVE_OP_MAXPOOL 1    /* 3x3 / stride 2 / pad 1 */
+#define SALVE_OP_AVGPOOL_FC 2 /* global average pool + linear layer -> fp32 logits */
+#define SALVE_NET_INPUT (-1)  /* buffer id of the network input */
+#define SALVE_NO_BUF (-2)     /* "no residual" */
+
+typedef struct {
+    int32_t op;
+    int32_t in_buf, out_buf, res_buf; /* activation buffer ids (SALVE_NET_INPUT / SALVE_NO_BUF) */
+    int32_t Hi, Wi, Cin;              /* input  H, W, channels (channels padded to a multiple of 8) */
+    int32_t Ho, Wo, Cout;             /* output H, W, channels (FC: Cout = number of classes) */
+    int32_t KH, KW, stride, pad;      /* KW is the PADDED kernel width of the packed weights */
+    int32_t relu, reserved;
+    int64_t w_off;    /* CONV: element offset into the bf16 weight blob; FC: float offset of the weight in params */
+    int64_t b_off;    /* float offset of the bias in params */
+    int64_t ktab_off; /* CONV: offset into ktab; one int32 per 8 consecutive k: dy | dx << 8 | channel_offset << 16 */
+} salve_resnet_op_t;
+
+/* Creates a handle that owns device copies of the (host) weight blobs.  NULL on failure. */
+void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,
+                          const void* weights_bf16, size_t weights_bytes, const float* params_f32, size_t params_bytes,
+                          const int32_t* ktab, size_t ktab_entries);
+void salve_resnet_destroy(void* handle);
+int salve_resnet_num_layers(void* handle);
+/* Device workspace needed for a batch (activation buffers). */
+size_t salve_resnet_workspace_bytes(void* handle, int32_t batch);
+/* input: device bf16 [batch, H, W, in_channels] (NHWC); logits: device float [batch, n_classes]. */
+int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* logits, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,17 +85,16 @@ def load() -> ctypes.CDLL:
     lib.salve_bev_export_u8.restype = ctypes.c_int
     lib.salve_bev_tiles.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
     lib.salve_bev_tiles.restype = ctypes.c_int
-    if hasattr(lib, "salve_resnet_create"):
-        lib.salve_resnet_create.argtypes = [i32, i32, i32, i32, vp, ctypes.c_int64, vp]
-        lib.salve_resnet_create.restype = vp
-        lib.salve_resnet_destroy.argtypes = [vp]
-        lib.salve_resnet_destroy.restype = None
-        lib.salve_resnet_workspace_bytes.argtypes = [vp, i32]
-        lib.salve_resnet_workspace_bytes.restype = sz
-        lib.salve_resnet_forward.argtypes = [vp, vp, i32, vp, vp, sz, vp]
-        lib.salve_resnet_forward.restype = ctypes.c_int
-        lib.salve_resnet_num_layers.argtypes = [vp]
-        lib.salve_resnet_num_layers.restype = ctypes.c_int
+    lib.salve_resnet_create.argtypes = [i32, i32, vp, i32, vp, sz, vp, sz, vp, sz]
+    lib.salve_resnet_create.restype = vp
+    lib.salve_resnet_destroy.argtypes = [vp]
+    lib.salve_resnet_destroy.restype = None
+    lib.salve_resnet_workspace_bytes.argtypes = [vp, i32]
+    lib.salve_resnet_workspace_bytes.restype = sz
+    lib.salve_resnet_forward.argtypes = [vp, vp, i32, vp, vp, sz, vp]
+    lib.salve_resnet_forward.restype = ctypes.c_int
+    lib.salve_resnet_num_layers.argtypes = [vp]
+    lib.salve_resnet_num_layers.restype = ctypes.c_int
     _lib = lib
     return lib
 

@@ -42,6 +42,7 @@ struct DevCfg {
     double rp00, rp01, rp10, rp11;
     double zlo[2], zhi[2], zmin;
     int nslices;
+    int dbg_flags;  // development only: 1 = skip the star phase, 2 = walk stars but do not rasterise
 };
 
 // ------------------------------------------------------------------------------------------------ scatter
@@ -122,6 +123,7 @@ struct RasterEmit {
     const uint32_t* msk;
     const unsigned long long* keys;
     uint32_t* bev;  // flipped output image of this render
+    bool skip;
 
     __device__ __forceinline__ uint32_t blend(int32_t wa, int32_t wb, int32_t wc, int32_t area, uint32_t ca,
                                               uint32_t cb, uint32_t cc) const {
@@ -139,7 +141,7 @@ struct RasterEmit {
 
     __device__ __forceinline__ void operator()(int ax, int ay, int bx, int by, int cx, int cy) const {
         const int32_t area = sd_orient(ax, ay, bx, by, cx, cy);
-        if (area <= 0) return;
+        if (area <= 0 || skip) return;
         int x0 = min(ax, min(bx, cx)), x1 = max(ax, max(bx, cx));
         const int y0 = min(ay, min(by, cy)), y1 = max(ay, max(by, cy));
         uint32_t ca = 0, cb = 0, cc = 0;
@@ -333,9 +335,9 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
     // ---- phase E: Delaunay stars + rasterisation of owned triangles.
-    if (!degenerate) {
+    if (!degenerate && !(c.dbg_flags & 1)) {
         SdGrid g = {H, W, wpr, occ, rmin, rmax};
-        RasterEmit emit = {H, W, wpr, occ, msk, keys, bev};
+        RasterEmit emit = {H, W, wpr, occ, msk, keys, bev, (c.dbg_flags & 2) != 0};
         int steps = 0, err = 0;
         for (int i = tid; i < nsites; i += DENSIFY_THREADS) {
             const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -425,7 +427,7 @@ bool make_devcfg(const salve_bev_config_t* cfg, DevCfg* d) {
     d->tx = cfg->img_tx; d->ty = cfg->img_ty; d->scale = cfg->img_scale;
     d->rp00 = cfg->rot_pre[0]; d->rp01 = cfg->rot_pre[1]; d->rp10 = cfg->rot_pre[2]; d->rp11 = cfg->rot_pre[3];
     for (int i = 0; i < 2; i++) { d->zlo[i] = cfg->z_lo[i]; d->zhi[i] = cfg->z_hi[i]; }
-    d->zmin = cfg->z_min; d->nslices = cfg->n_slices;
+    d->zmin = cfg->z_min; d->nslices = cfg->n_slices; d->dbg_flags = cfg->reserved1;
     const int ntasks = ((d->H + MASK_ROWS_PER_TASK - 1) / MASK_ROWS_PER_TASK) * d->wpr;
     if (ntasks > DENSIFY_THREADS) return salve_fail("bev image too large for the LDS mask pass");
     return true;

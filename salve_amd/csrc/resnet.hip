@@ -1,0 +1,380 @@
+// resnet.hip -- early-fusion ResNet verifier forward pass for gfx950 (MI355X), bf16 MFMA with fp32 accumulation.
+//
+// Stands behind salve/models/early_fusion.py:41-83 (EarlyFusionCEResnet.forward) with the torchvision ResNet v1.5
+// trunk built by salve/models/resnet_factory.py:26-44.  The host (salve_amd/models) folds every BatchNorm into the
+// preceding convolution, packs weights as [Cout][KH][KWp][Cin] bf16 and hands the network over as a small "op
+// program" (salve_resnet_op_t): CONV (+bias, +residual, ReLU), MAXPOOL 3x3/2, AVGPOOL+FC.  The library just runs it.
+//
+// Convolution = implicit GEMM on NHWC bf16 activations:  out[m, n] = sum_k A[m, k] W[n, k],  m = (b, oy, ox),
+// k = (kh, kw, ci).  Block tile 128 x BN x 64, four waves (2 x 2), v_mfma_f32_16x16x32_bf16, the im2col gather of
+// A staged global -> registers -> LDS one k-tile ahead of the MFMAs (issue-early / write-late), epilogue through
+// LDS so that the residual read and the output store are 16-byte coalesced.  The 7x7/2 stem runs through the same
+// kernel: input channels are padded to 8 (or 16) and kw to 8 so that one k-tile is one kernel row.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/salve_hip.h"
+#include "salve_common.h"
+
+namespace {
+
+typedef __attribute__((__ext_vector_type__(8))) __bf16 bf16x8;
+typedef __attribute__((__ext_vector_type__(4))) float f32x4;
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int LDK = BK + 8;  // LDS row stride in elements (144 B): conflict-free 16-byte fragment reads
+constexpr int CONV_THREADS = 256;
+
+struct ConvArgs {
+    const uint16_t* in;
+    const uint16_t* w;
+    const float* bias;
+    const uint16_t* res;
+    uint16_t* out;
+    const int32_t* ktab;  // per 8-element chunk of K: dy | dx << 8 | channel offset << 16
+    int B, Hi, Wi, Cin, Ho, Wo, Cout, stride, pad, K, M, relu;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // keep NaNs NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <int BN>
+__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int WN = BN / 2;       // wave tile width
+    constexpr int NT = WN / 16;      // 16-wide MFMA tiles per wave along n
+    constexpr int B_LOADS = BN / 32; // 16-byte chunks of the weight tile per thread
+    constexpr int LDC = BN + 8;
+    constexpr int AB_ELEMS = (BM + BN) * LDK;
+    constexpr int C_ELEMS = BM * LDC;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[AB_ELEMS > C_ELEMS ? AB_ELEMS : C_ELEMS];
+    uint16_t* As = smem;
+    uint16_t* Bs = smem + BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int chunk = tid & 7;  // which 16-byte chunk of the 64-wide k-tile this thread stages
+    const int row_base = tid >> 3;  // 0..31, plus i * 32
+
+    // per-thread im2col rows (fixed for the whole K loop)
+    int iy0[4], ix0[4];
+    long long boff[4];
+    bool rvalid[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = m0 + row_base + i * 32;
+        rvalid[i] = m < p.M;
+        const int mm = rvalid[i] ? m : 0;
+        const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+        iy0[i] = oy * p.stride - p.pad;
+        ix0[i] = ox * p.stride - p.pad;
+        boff[i] = (long long)b * p.Hi * p.Wi;
+    }
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[B_LOADS];
+    const int nkt = p.K / BK;
+
+    auto load_tile = [&](int kt) {
+        const int32_t e = p.ktab[kt * 8 + chunk];
+        const int dy = (int8_t)(e & 0xFF), dx = (int8_t)((e >> 8) & 0xFF), coff = (e >> 16) & 0xFFFF;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            const bool ok = rvalid[i] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(p.in + ((boff[i] + (long long)iy * p.Wi + ix) * p.Cin + coff))
+                       : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; i++) {
+            const int n = n0 + row_base + i * 32;
+            rb[i] = *reinterpret_cast<const uint4*>(p.w + (long long)n * p.K + kt * BK + chunk * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(As + (row_base + i * 32) * LDK + chunk * 8) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LOADS; i++) *reinterpret_cast<uint4*>(Bs + (row_base + i * 32) * LDK + chunk * 8) = rb[i];
+    };
+
+    load_tile(0);
+    for (int kt = 0; kt < nkt; kt++) {
+        __syncthreads();  // previous tile's fragment reads are done
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);  // in flight under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ks++) {
+            bf16x8 af[4], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                af[i] = *reinterpret_cast<const bf16x8*>(As + (wr * 64 + i * 16 + (lane & 15)) * LDK + ks * 32 + (lane >> 4) * 8);
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + (wc * WN + j * 16 + (lane & 15)) * LDK + ks * 32 + (lane >> 4) * 8);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: (residual tile ->) LDS, add bias / residual / ReLU in fp32 on the accumulator's own elements,
+    //      round once to bf16, then 16-byte coalesced stores.
+    __syncthreads();
+    uint16_t* Cs = smem;
+    constexpr int CH_PER_ROW = BN / 8;
+    constexpr int C_ITERS = (BM * CH_PER_ROW) / CONV_THREADS;
+    if (p.res) {
+#pragma unroll
+        for (int it = 0; it < C_ITERS; it++) {
+            const int id = tid + it * CONV_THREADS;
+            const int r = id / CH_PER_ROW, ch = id % CH_PER_ROW;
+            const int m = m0 + r;
+            uint4 v = uint4{0u, 0u, 0u, 0u};
+            if (m < p.M) v = *reinterpret_cast<const uint4*>(p.res + (long long)m * p.Cout + n0 + ch * 8);
+            *reinterpret_cast<uint4*>(Cs + r * LDC + ch * 8) = v;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int ncol = wc * WN + j * 16 + (lane & 15);
+        const float bias = p.bias[n0 + ncol];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int mrow = wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+                float v = acc[i][j][r] + bias;
+                if (p.res) v += bf16_to_f32(Cs[mrow * LDC + ncol]);
+                if (p.relu) v = fmaxf(v, 0.f);
+                Cs[mrow * LDC + ncol] = f32_to_bf16(v);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < C_ITERS; it++) {
+        const int id = tid + it * CONV_THREADS;
+        const int r = id / CH_PER_ROW, ch = id % CH_PER_ROW;
+        const int m = m0 + r;
+        if (m < p.M)
+            *reinterpret_cast<uint4*>(p.out + (long long)m * p.Cout + n0 + ch * 8) = *reinterpret_cast<const uint4*>(Cs + r * LDC + ch * 8);
+    }
+}
+
+// 3x3 / stride 2 / pad 1 max-pool on NHWC bf16, 8 channels (16 bytes) per thread.
+__global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B,
+                                                      int Hi, int Wi, int C, int Ho, int Wo) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = C / 8;
+    const long long total = (long long)B * Ho * Wo * c8;
+    if (idx >= total) return;
+    const int ch = (int)(idx % c8);
+    long long t = idx / c8;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float best[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) best[k] = -3.0e38f;
+    for (int dy = 0; dy < 3; dy++) {
+        const int iy = oy * 2 - 1 + dy;
+        if (iy < 0 || iy >= Hi) continue;
+        for (int dx = 0; dx < 3; dx++) {
+            const int ix = ox * 2 - 1 + dx;
+            if (ix < 0 || ix >= Wi) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(in + (((long long)b * Hi + iy) * Wi + ix) * C + ch * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                best[2 * k] = fmaxf(best[2 * k], bf16_to_f32((uint16_t)(w[k] & 0xFFFFu)));
+                best[2 * k + 1] = fmaxf(best[2 * k + 1], bf16_to_f32((uint16_t)(w[k] >> 16)));
+            }
+        }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = (uint32_t)f32_to_bf16(best[2 * k]) | ((uint32_t)f32_to_bf16(best[2 * k + 1]) << 16);
+    *reinterpret_cast<uint4*>(out + (((long long)b * Ho + oy) * Wo + ox) * C + ch * 8) = uint4{o[0], o[1], o[2], o[3]};
+}
+
+// Global average pool over HW positions + fully connected layer (fp32 weights), one block per sample.
+__global__ __launch_bounds__(256) void avgpool_fc_kernel(const uint16_t* __restrict__ in, int HW, int C,
+                                                         const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                                         int ncls, float* __restrict__ logits) {
+    extern __shared__ float red[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint16_t* x = in + (long long)b * HW * C;
+    float part[8];  // ncls <= 8
+#pragma unroll
+    for (int k = 0; k < 8; k++) part[k] = 0.f;
+    const float inv = 1.0f / (float)HW;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int i = 0; i < HW; i++) s += bf16_to_f32(x[(long long)i * C + c]);
+        s *= inv;
+        for (int k = 0; k < ncls; k++) part[k] += s * fcw[(long long)k * C + c];
+    }
+    for (int k = 0; k < ncls; k++) {
+        red[tid] = part[k];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) logits[(long long)b * ncls + k] = red[0] + fcb[k];
+        __syncthreads();
+    }
+}
+
+struct ResnetHandle {
+    std::vector<salve_resnet_op_t> ops;
+    uint16_t* d_weights = nullptr;
+    float* d_params = nullptr;
+    int32_t* d_ktab = nullptr;
+    size_t max_act_elems = 0;  // per sample, elements of the largest activation buffer
+    int n_bufs = 0;
+    int num_layers = 0, in_channels = 0, ncls = 0;
+};
+
+bool check_op(const salve_resnet_op_t& o) {
+    if (o.op == SALVE_OP_CONV) {
+        if (o.Cout % 64 != 0) return salve_fail("conv: Cout must be a multiple of 64");
+        if (o.Cin % 8 != 0) return salve_fail("conv: Cin must be a multiple of 8");
+        if ((o.KH * o.KW * o.Cin) % BK != 0) return salve_fail("conv: KH*KW*Cin must be a multiple of 64");
+    } else if (o.op == SALVE_OP_MAXPOOL) {
+        if (o.Cin % 8 != 0) return salve_fail("maxpool: C must be a multiple of 8");
+    } else if (o.op == SALVE_OP_AVGPOOL_FC) {
+        if (o.Cout < 1 || o.Cout > 8) return salve_fail("fc: 1..8 classes supported");
+    } else {
+        return salve_fail("unknown op");
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,
+                          const void* weights_bf16, size_t weights_bytes, const float* params_f32, size_t params_bytes,
+                          const int32_t* ktab, size_t ktab_entries) {
+    if (!ops || n_ops <= 0 || !weights_bf16 || !params_f32 || !ktab) {
+        salve_fail("salve_resnet_create: null argument");
+        return nullptr;
+    }
+    ResnetHandle* h = new ResnetHandle();
+    h->num_layers = num_layers;
+    h->in_channels = in_channels;
+    for (int i = 0; i < n_ops; i++) {
+        if (!check_op(ops[i])) { delete h; return nullptr; }
+        h->ops.push_back(ops[i]);
+        const salve_resnet_op_t& o = ops[i];
+        if (o.op != SALVE_OP_AVGPOOL_FC) {
+            const size_t e = (size_t)o.Ho * o.Wo * o.Cout;
+            if (e > h->max_act_elems) h->max_act_elems = e;
+            if (o.out_buf + 1 > h->n_bufs) h->n_bufs = o.out_buf + 1;
+        } else {
+            h->ncls = o.Cout;
+        }
+    }
+    if (hipMalloc(&h->d_weights, weights_bytes) != hipSuccess || hipMalloc(&h->d_params, params_bytes) != hipSuccess ||
+        hipMalloc(&h->d_ktab, ktab_entries * sizeof(int32_t)) != hipSuccess) {
+        salve_fail("salve_resnet_create: hipMalloc failed");
+        salve_resnet_destroy(h);
+        return nullptr;
+    }
+    if (hipMemcpy(h->d_weights, weights_bf16, weights_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_params, params_f32, params_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_ktab, ktab, ktab_entries * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        salve_fail("salve_resnet_create: hipMemcpy failed");
+        salve_resnet_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+void salve_resnet_destroy(void* handle) {
+    ResnetHandle* h = reinterpret_cast<ResnetHandle*>(handle);
+    if (!h) return;
+    if (h->d_weights) (void)hipFree(h->d_weights);
+    if (h->d_params) (void)hipFree(h->d_params);
+    if (h->d_ktab) (void)hipFree(h->d_ktab);
+    delete h;
+}
+
+int salve_resnet_num_layers(void* handle) { return handle ? reinterpret_cast<ResnetHandle*>(handle)->num_layers : 0; }
+
+size_t salve_resnet_workspace_bytes(void* handle, int32_t batch) {
+    ResnetHandle* h = reinterpret_cast<ResnetHandle*>(handle);
+    if (!h || batch <= 0) return 0;
+    return (size_t)h->n_bufs * (size_t)batch * h->max_act_elems * sizeof(uint16_t) + 256;
+}
+
+int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* logits, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    ResnetHandle* h = reinterpret_cast<ResnetHandle*>(handle);
+    if (!h || !input || !logits || !workspace || batch <= 0) {
+        salve_fail("salve_resnet_forward: null argument or bad batch");
+        return SALVE_ERR_BAD_ARG;
+    }
+    if (workspace_bytes < salve_resnet_workspace_bytes(handle, batch)) {
+        salve_fail("salve_resnet_forward: workspace too small");
+        return SALVE_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    uint16_t* base = reinterpret_cast<uint16_t*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const size_t buf_elems = (size_t)batch * h->max_act_elems;
+    auto buf = [&](int i) -> uint16_t* { return i < 0 ? const_cast<uint16_t*>(reinterpret_cast<const uint16_t*>(input)) : base + (size_t)i * buf_elems; };
+    for (const salve_resnet_op_t& o : h->ops) {
+        if (o.op == SALVE_OP_CONV) {
+            ConvArgs a;
+            a.in = buf(o.in_buf);
+            a.w = h->d_weights + o.w_off;
+            a.bias = h->d_params + o.b_off;
+            a.res = o.res_buf != SALVE_NO_BUF ? buf(o.res_buf) : nullptr;
+            a.out = buf(o.out_buf);
+            a.ktab = h->d_ktab + o.ktab_off;
+            a.B = batch; a.Hi = o.Hi; a.Wi = o.Wi; a.Cin = o.Cin; a.Ho = o.Ho; a.Wo = o.Wo; a.Cout = o.Cout;
+            a.stride = o.stride; a.pad = o.pad; a.K = o.KH * o.KW * o.Cin; a.relu = o.relu;
+            const long long M = (long long)batch * o.Ho * o.Wo;
+            if (M > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
+            a.M = (int)M;
+            const int gm = (int)((M + BM - 1) / BM);
+            if (o.Cout % 128 == 0) {
+                hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(gm, o.Cout / 128), dim3(CONV_THREADS), 0, s, a);
+            } else {
+                hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(gm, o.Cout / 64), dim3(CONV_THREADS), 0, s, a);
+            }
+        } else if (o.op == SALVE_OP_MAXPOOL) {
+            const long long total = (long long)batch * o.Ho * o.Wo * (o.Cin / 8);
+            hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, buf(o.in_buf), buf(o.out_buf),
+                               batch, o.Hi, o.Wi, o.Cin, o.Ho, o.Wo);
+        } else {
+            hipLaunchKernelGGL(avgpool_fc_kernel, dim3(batch), dim3(256), 256 * sizeof(float), s, buf(o.in_buf), o.Hi * o.Wi,
+                               o.Cin, h->d_params + o.w_off, h->d_params + o.b_off, o.Cout, logits);
+        }
+        SALVE_HIP_CHECK(hipGetLastError());
+    }
+    return SALVE_OK;
+}
+
+}  // extern "C"

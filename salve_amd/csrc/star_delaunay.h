@@ -39,17 +39,19 @@ SD_FN int32_t sd_orient(int ax, int ay, int bx, int by, int cx, int cy) {
 
 SD_FN bool sd_before(int ax, int ay, int bx, int by) { return ay < by || (ay == by && ax < bx); }
 
-// > 0 iff d strictly inside the circle through a, b, c (a, b, c counter-clockwise); exact.
-SD_FN int64_t sd_incircle(int ax, int ay, int bx, int by, int cx, int cy, int dx, int dy) {
-    int64_t adx = ax - dx, ady = ay - dy, bdx = bx - dx, bdy = by - dy, cdx = cx - dx, cdy = cy - dy;
-    int64_t ad = adx * adx + ady * ady, bd = bdx * bdx + bdy * bdy, cd = cdx * cdx + cdy * cdy;
+// > 0 iff d strictly inside the circle through a, b, c (a, b, c counter-clockwise).  Evaluated in float64, which is
+// EXACT here: every intermediate is an integer below 2^48 (|coordinate difference| < 2^11), far inside the 53-bit
+// significand -- and float64 runs at half the float32 rate on MI355X while 64-bit integer multiplies are emulated.
+SD_FN double sd_incircle(int ax, int ay, int bx, int by, int cx, int cy, int dx, int dy) {
+    const double adx = ax - dx, ady = ay - dy, bdx = bx - dx, bdy = by - dy, cdx = cx - dx, cdy = cy - dy;
+    const double ad = adx * adx + ady * ady, bd = bdx * bdx + bdy * bdy, cd = cdx * cdx + cdy * cdy;
     return adx * (bdy * cd - bd * cdy) - ady * (bdx * cd - bd * cdx) + ad * (bdx * cdy - bdy * cdx);
 }
 
 // Perturbed in-circle test, never a tie: true iff d is inside circle(a, b, c), a,b,c counter-clockwise.
 SD_FN bool sd_inside(int ax, int ay, int bx, int by, int cx, int cy, int dx, int dy) {
-    int64_t det = sd_incircle(ax, ay, bx, by, cx, cy, dx, dy);
-    if (det != 0) return det > 0;
+    const double det = sd_incircle(ax, ay, bx, by, cx, cy, dx, dy);
+    if (det != 0.0) return det > 0.0;
     // co-circular: the raster-first site carries the dominant perturbation
     bool a_first = sd_before(ax, ay, bx, by) && sd_before(ax, ay, cx, cy) && sd_before(ax, ay, dx, dy);
     bool b_first = sd_before(bx, by, ax, ay) && sd_before(bx, by, cx, cy) && sd_before(bx, by, dx, dy);
@@ -100,7 +102,7 @@ SD_FN int sd_ctz(uint32_t v) {
 
 // Nearest site to s (any one of the nearest on ties).  Returns false iff s is the only site.
 SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
-    int64_t best = INT64_MAX;
+    int32_t best = INT32_MAX;
     int bx = -1, by = -1;
     int R = 2;
     for (;;) {
@@ -114,12 +116,12 @@ SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
                     int x = (w << 5) + sd_ctz(bits);
                     bits &= bits - 1;
                     if (x == sx && y == sy) continue;
-                    int64_t d2 = (int64_t)(x - sx) * (x - sx) + (int64_t)(y - sy) * (y - sy);
+                    const int32_t d2 = (x - sx) * (x - sx) + (y - sy) * (y - sy);
                     if (d2 < best) { best = d2; bx = x; by = y; }
                 }
             }
         }
-        if (best <= (int64_t)R * R) break;                                   // nothing outside the window is closer
+        if (best <= R * R) break;                                   // nothing outside the window is closer
         if (x0 == 0 && y0 == 0 && x1 == g.W - 1 && y1 == g.H - 1) break;    // whole image searched
         R *= 2;
     }
@@ -128,33 +130,73 @@ SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
     return bx >= 0;
 }
 
-// Scan rows [ya, yb] for a better apex of edge s->a on side dir.  (px,py) < 0 means "none yet".
-// The x-range of each row is cut to the current circle (a superset with a one-pixel margin), so the work shrinks
-// as the apex improves; rows are cut to the occupied extent.
-SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int ya, int yb, int xa, int xb,
-                        int* px, int* py, SdCircle* circ) {
-    for (int y = ya; y <= yb; y++) {
+#ifndef SD_COUNT
+#define SD_COUNT(counter)
+#endif
+
+// Scan rows ya, ya+step, ..., yb (step = +1 or -1), columns [xa, xb], for a better apex of the directed edge
+// s->a on side dir.  (px,py) < 0 means "none yet".  Rows are cut to their occupied extent; wide scans are also cut,
+// before the bitmap is touched, to the open half-plane on side dir of the line s->a and to the current candidate
+// circle (supersets with a safety margin), so rows on the wrong side cost a few instructions and the work shrinks
+// as the apex improves.  A sweep stops once it has left the circle in its direction of travel.  Every surviving
+// bit is tested with the exact predicates.
+SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int ya, int yb, int step, int xa,
+                        int xb, int* px, int* py, SdCircle* circ) {
+    const bool wide = xb - xa > 48;
+    // dir * orient(s, a, (x, y)) = P (y - sy) - Q (x - sx) >= 1
+    const double P = (double)(dir * (ax - sx)), Q = (double)(dir * (ay - sy));
+    const double invQ = Q != 0.0 ? 1.0 / Q : 0.0;
+    for (int y = ya; step > 0 ? y <= yb : y >= yb; y += step) {
+        SD_COUNT(rows);
         int x0 = xa > g.rmin[y] ? xa : g.rmin[y];
         int x1 = xb < g.rmax[y] ? xb : g.rmax[y];
-        if (*px >= 0) {
-            double dy = y - circ->oy;
-            double h2 = circ->r2 - dy * dy;
-            double r1 = sqrt(circ->r2) + 1.0;
-            if (dy > r1 || -dy > r1) continue;
-            // h2 carries a round-off of a few ulp of r^2 (r can reach 2.5e8 px for sliver triangles): widen by it
-            double half = sqrt((h2 > 0 ? h2 : 0.0) + 4e-15 * circ->r2) + 1.0;
-            double lo = floor(circ->ox - half), hi = ceil(circ->ox + half);
-            if (lo > x0) x0 = lo > 1e9 ? g.W : (int)lo;
-            if (hi < x1) x1 = hi < -1e9 ? -1 : (int)hi;
-        }
         if (x0 > x1) continue;
+        if (*px >= 0) {
+            const double dy = y - circ->oy;
+            if (dy * dy > circ->r2 + 2.0 * sqrt(circ->r2) + 1.0) {  // |dy| > r + 1
+                if (step > 0 ? dy > 0 : dy < 0) break;             // left the circle for good
+                continue;
+            }
+        }
+        if (wide) {
+            const double T = P * (double)(y - sy) - 1.0;
+            if (Q == 0.0) {
+                if (T < 0.0) continue;
+            } else {
+                const double t = T * invQ;  // Q u <= T  with u = x - sx
+                if (Q > 0.0) {
+                    const double hi = floor(t) + 1.0 + sx;
+                    if (hi < x1) x1 = hi < -1.0 ? -1 : (int)hi;
+                } else {
+                    const double lo = ceil(t) - 1.0 + sx;
+                    if (lo > x0) x0 = lo > 1e9 ? g.W : (int)lo;
+                }
+                if (x0 > x1) continue;
+            }
+            if (*px >= 0) {
+                const double dy = y - circ->oy;
+                const double h2 = circ->r2 - dy * dy;
+                // h2 carries a round-off of a few ulp of r^2 (r can reach 2.5e8 px for sliver triangles): widen by it
+                const double half = sqrt((h2 > 0 ? h2 : 0.0) + 4e-15 * circ->r2) + 1.0;
+                const double lo = floor(circ->ox - half), hi = ceil(circ->ox + half);
+                if (lo > x0) x0 = lo > 1e9 ? g.W : (int)lo;
+                if (hi < x1) x1 = hi < -1e9 ? -1 : (int)hi;
+                if (x0 > x1) continue;
+            }
+        }
         for (int w = x0 >> 5; w <= (x1 >> 5); w++) {
             uint32_t bits = sd_word_bits(g, y, w, x0, x1);
             while (bits) {
                 int x = (w << 5) + sd_ctz(bits);
                 bits &= bits - 1;
+                SD_COUNT(bits);
                 int32_t o = sd_orient(sx, sy, ax, ay, x, y);
                 if (dir > 0 ? o <= 0 : o >= 0) continue;  // wrong side, collinear, or s / a themselves
+                if (*px >= 0) {  // cheap float reject: clearly outside the candidate circle
+                    const double ex = x - circ->ox, ey = y - circ->oy;
+                    if (ex * ex + ey * ey > circ->r2 * (1.0 + 1e-9) + 1e-3) continue;
+                }
+                SD_COUNT(exact);
                 if (*px < 0 || sd_better(sx, sy, ax, ay, *px, *py, x, y, dir)) {
                     *px = x;
                     *py = y;
@@ -165,36 +207,47 @@ SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir
     }
 }
 
+#ifndef SD_WINDOW_MARGIN
+#define SD_WINDOW_MARGIN 2
+#endif
+
 // Apex of the Delaunay triangle on side dir of the Delaunay edge s->a.  Returns false iff there is no site
 // strictly on that side, i.e. s->a is a hull edge.
 SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int* outx, int* outy) {
     int px = -1, py = -1;
     SdCircle circ = {0, 0, 0};
+    SD_COUNT(apex);
     // 1. a small window around the edge finds the apex in dense regions
-    const int M = 3;
+    const int M = SD_WINDOW_MARGIN;
     int wy0 = (sy < ay ? sy : ay) - M, wy1 = (sy > ay ? sy : ay) + M;
     int wx0 = (sx < ax ? sx : ax) - M, wx1 = (sx > ax ? sx : ax) + M;
     if (wy0 < 0) wy0 = 0;
     if (wx0 < 0) wx0 = 0;
     if (wy1 > g.H - 1) wy1 = g.H - 1;
     if (wx1 > g.W - 1) wx1 = g.W - 1;
-    sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, wx0, wx1, &px, &py, &circ);
+    sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, wx0, wx1, &px, &py, &circ);
     if (px >= 0) {
-        // 2. the candidate's circle may stick out of the window: sweep what is left of its bounding box
-        double r = sqrt(circ.r2) + 2.0;
-        double fy0 = circ.oy - r, fy1 = circ.oy + r, fx0 = circ.ox - r, fx1 = circ.ox + r;
-        int ya = fy0 <= 0 ? 0 : (int)fy0, yb = fy1 >= g.H - 1 ? g.H - 1 : (int)fy1 + 1;
-        int xa = fx0 <= 0 ? 0 : (int)fx0, xb = fx1 >= g.W - 1 ? g.W - 1 : (int)fx1 + 1;
-        if (yb > g.H - 1) yb = g.H - 1;
-        if (xb > g.W - 1) xb = g.W - 1;
-        if (ya < wy0) sd_scan_rows(g, sx, sy, ax, ay, dir, ya, wy0 - 1, xa, xb, &px, &py, &circ);
-        if (yb > wy1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy1 + 1, yb, xa, xb, &px, &py, &circ);
-        if (xa < wx0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, xa, wx0 - 1, &px, &py, &circ);
-        if (xb > wx1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, wx1 + 1, xb, &px, &py, &circ);
+        // 2. whatever part of the candidate's circle sticks out of the window (and is on the image) is swept too
+        const double r = sqrt(circ.r2) + 1.0;
+        const double fy0 = circ.oy - r, fy1 = circ.oy + r, fx0 = circ.ox - r, fx1 = circ.ox + r;
+        const int cy0 = fy0 <= 0 ? 0 : (int)fy0, cx0 = fx0 <= 0 ? 0 : (int)fx0;
+        const int cy1 = fy1 >= g.H - 1 ? g.H - 1 : (int)fy1 + 1, cx1 = fx1 >= g.W - 1 ? g.W - 1 : (int)fx1 + 1;
+        if (cy1 > wy1 || cy0 < wy0 || cx0 < wx0 || cx1 > wx1) {
+            SD_COUNT(apex_slow);
+            if (cy1 > wy1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy1 + 1, cy1, 1, cx0, cx1, &px, &py, &circ);
+            if (cy0 < wy0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0 - 1, cy0, -1, cx0, cx1, &px, &py, &circ);
+            const int ry0 = cy0 > wy0 ? cy0 : wy0, ry1 = cy1 < wy1 ? cy1 : wy1;
+            if (cx0 < wx0) sd_scan_rows(g, sx, sy, ax, ay, dir, ry0, ry1, 1, cx0, wx0 - 1, &px, &py, &circ);
+            if (cx1 > wx1) sd_scan_rows(g, sx, sy, ax, ay, dir, ry0, ry1, 1, wx1 + 1, cx1, &px, &py, &circ);
+        }
     } else {
-        // 3. nothing near the edge: sweep the whole image (rows are cut to their occupied extent, and to the
-        //    circle as soon as a first candidate turns up).  An empty result means s->a is a hull edge.
-        sd_scan_rows(g, sx, sy, ax, ay, dir, 0, g.H - 1, 0, g.W - 1, &px, &py, &circ);
+        // 3. nothing near the edge: the window's rows outside its columns, then away from the window downwards
+        //    and upwards.  An empty result means s->a is a hull edge.
+        SD_COUNT(apex_far);
+        if (wx0 > 0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, 0, wx0 - 1, &px, &py, &circ);
+        if (wx1 < g.W - 1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, wx1 + 1, g.W - 1, &px, &py, &circ);
+        if (wy1 < g.H - 1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy1 + 1, g.H - 1, 1, 0, g.W - 1, &px, &py, &circ);
+        if (wy0 > 0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0 - 1, 0, -1, 0, g.W - 1, &px, &py, &circ);
     }
     *outx = px;
     *outy = py;

@@ -1,0 +1,134 @@
+"""GPU parity of the HIP ResNet verifier (bf16 MFMA) against the fp32 CPU oracle, through the C ABI."""
+
+import ctypes
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import resnet_oracle as ro  # noqa: E402
+from salve_amd import _lib  # noqa: E402
+from salve_amd.models import hip_resnet  # noqa: E402
+from salve_amd.models.early_fusion import EarlyFusionCEResnet  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def randomise_bn(model, seed=0):
+    """Trained-looking BatchNorm statistics so that activations stay O(1) through the trunk."""
+    g = torch.Generator().manual_seed(seed)
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            last = name.endswith("bn3") or (name.endswith("bn2") and model.resnet.block_kind == "basic")
+            m.weight.data = (0.25 if last else 1.0) * (0.6 + 0.4 * torch.rand(m.num_features, generator=g))
+            m.bias.data = 0.1 * torch.randn(m.num_features, generator=g)
+            m.running_mean.data = 0.1 * torch.randn(m.num_features, generator=g)
+            m.running_var.data = 0.6 + 0.8 * torch.rand(m.num_features, generator=g)
+
+
+def run_single_conv(w, b, x_nhwc, stride, pad, relu, res=None, kw_pad=0):
+    """One CONV op through salve_resnet_create / salve_resnet_forward; returns the bf16 NHWC output as fp32."""
+    lib = _lib.load()
+    bld = hip_resnet._Builder()
+    B, Hi, Wi, Cp = x_nhwc.shape
+    Ho, Wo = bld.conv(w, b, hip_resnet.NET_INPUT, 0, hip_resnet.NO_BUF if res is None else 1, Hi, Wi, stride, pad, relu, kw_pad)
+    ops = np.array(bld.ops, dtype=hip_resnet.OP_DTYPE)
+    wb, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
+    if res is not None:  # make the handle size two buffers
+        ops = np.concatenate([ops, ops])
+        ops[1]["out_buf"] = 1
+        ops = ops[:1] if False else ops
+    h = lib.salve_resnet_create(0, Cp, ops.ctypes.data_as(ctypes.c_void_p), len(ops), wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
+                                pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size)
+    assert h
+    h = ctypes.c_void_p(h)
+    need = lib.salve_resnet_workspace_bytes(h, B)
+    ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
+    Cout = w.shape[0]
+    per_buf = (need - 256) // (2 if res is not None else 1) // 2
+    base_off = (-ws.data_ptr()) % 256
+    view = ws[base_off:].view(torch.bfloat16)
+    if res is not None:
+        view[per_buf:per_buf + res.numel()] = res.reshape(-1).to(DEV)
+        ops1 = ops[:1]
+        lib.salve_resnet_destroy(h)
+        h = ctypes.c_void_p(lib.salve_resnet_create(0, Cp, ops.ctypes.data_as(ctypes.c_void_p), 1, wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
+                                                     pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
+        # one op, but the workspace keeps room for two buffers (the residual lives in buffer 1)
+    logits = torch.zeros((B, 2), dtype=torch.float32, device=DEV)
+    xd = x_nhwc.to(DEV).contiguous()
+    st = lib.salve_resnet_forward(h, ctypes.c_void_p(xd.data_ptr()), B, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                  ws.numel(), None)
+    torch.cuda.synchronize()
+    assert st == 0, lib.salve_last_error()
+    out = view[: B * Ho * Wo * Cout].float().cpu().reshape(B, Ho, Wo, Cout)
+    lib.salve_resnet_destroy(h)
+    return out
+
+
+@pytest.mark.parametrize("case", [
+    dict(cin=64, cout=64, k=1, s=1, p=0, hw=56, relu=True),
+    dict(cin=64, cout=256, k=1, s=1, p=0, hw=56, relu=False),
+    dict(cin=128, cout=128, k=3, s=2, p=1, hw=28, relu=True),
+    dict(cin=256, cout=512, k=1, s=2, p=0, hw=28, relu=False),
+    dict(cin=512, cout=512, k=3, s=1, p=1, hw=7, relu=True),
+    dict(cin=6, cout=64, k=7, s=2, p=3, hw=64, relu=True, kw_pad=8),
+    dict(cin=12, cout=64, k=7, s=2, p=3, hw=32, relu=True, kw_pad=8),
+])
+def test_conv_matches_torch(case):
+    g = torch.Generator().manual_seed(1)
+    B = 3
+    w = torch.randn(case["cout"], case["cin"], case["k"], case["k"], generator=g) * (2.0 / (case["cin"] * case["k"] ** 2)) ** 0.5
+    b = torch.randn(case["cout"], generator=g) * 0.1
+    x = torch.randn(B, case["cin"], case["hw"], case["hw"], generator=g)
+    cp = hip_resnet.pad_channels(case["cin"])
+    x_nhwc = torch.zeros(B, case["hw"], case["hw"], cp, dtype=torch.bfloat16)
+    x_nhwc[..., : case["cin"]] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    got = run_single_conv(w, b, x_nhwc, case["s"], case["p"], case["relu"], kw_pad=case.get("kw_pad", 0))
+    xr = x_nhwc[..., : case["cin"]].float().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xr, w.to(torch.bfloat16).float(), b, case["s"], case["p"])
+    if case["relu"]:
+        ref = ref.relu()
+    ref = ref.permute(0, 2, 3, 1)
+    err = (got - ref).abs()
+    tol = 2e-2 * ref.abs().clamp(min=0.5)  # two bf16 ulps of the output
+    assert (err <= tol).all(), f"max err {err.max()} at |ref| {ref.abs().max()}"
+
+
+@pytest.mark.parametrize("num_layers,modalities,batch", [
+    (50, ["floor_rgb_texture"], 5),
+    (152, ["ceiling_rgb_texture", "floor_rgb_texture"], 2),
+    (18, ["layout"], 3),
+])
+def test_logits_match_oracle(num_layers, modalities, batch):
+    """Tolerance: bf16 activations/weights with fp32 accumulation.  north_star asks 1e-3 on logits for the
+    fp path; bf16 storage (8 significand bits) cannot reach that, so the bound here is 3e-2 of the logit scale and
+    the measured error is printed."""
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(num_layers, False, 2, SimpleNamespace(modalities=modalities))
+    randomise_bn(model)
+    model.eval()
+    n = len(modalities) * 2
+    xs = [torch.randn(batch, 3, 224, 224) for _ in range(n)]
+    xs_b = [x.to(torch.bfloat16).float() for x in xs]  # the network input is bf16 on the GPU side
+    with torch.no_grad():
+        ref = ro.forward(model.state_dict(), num_layers, xs_b)
+        pad = xs + [None] * (6 - n)
+        got = model.to(DEV)(*[None if x is None else x.to(DEV) for x in pad]).cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    print(f"resnet{num_layers}: logits scale {scale:.3f}, max abs err {err:.4f}")
+    assert err <= 3e-2 * scale
+    assert (got.argmax(1) == ref.argmax(1)).all() or err < 1e-2
+
+
+def test_forward_refuses_cpu_and_bad_modalities():
+    model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["layout"])).eval()
+    x = torch.zeros(1, 3, 224, 224)
+    with pytest.raises(RuntimeError):
+        model(x, x, None, None, None, None)
+    with pytest.raises(RuntimeError):
+        EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["bogus"]))

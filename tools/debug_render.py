@@ -9,6 +9,8 @@ from salve_amd.rasteriser import BevRasteriser, pack_hypotheses
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device("cuda:0")
 ras = BevRasteriser(dev)
+import os
+ras.cfg.reserved1 = int(os.environ.get("SALVE_DBG_FLAGS", "0"))
 panos = [synthetic.make_pano(i) for i in range(2)]
 d_rgb, d_depth = ras.upload_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
 hyp = synthetic.make_hypotheses(max(n, 16), 2, seed=0)
