@@ -101,6 +101,15 @@ int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rg
                            uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
                            int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The two halves of salve_bev_render_batch as separate launches (same arguments, same workspace):
+ * salve_bev_scatter fills the z-order key images, salve_bev_densify turns them into BEV images.  Used by the
+ * benchmark to time the dominant kernel on its own; render_batch == scatter followed by densify. */
+int salve_bev_scatter(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth, int32_t n_panos,
+                      const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, int16_t* dbg_img_xy, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, uint64_t* dbg_keys, uint8_t* dbg_mask,
+                      int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream);
+
 /* BEV uint32 -> uint8 [n, bev_h, bev_w, 3], the array render_bev_image returns (bev_rendering_utils.py:328). */
 int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream);
 

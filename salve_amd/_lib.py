@@ -23,6 +23,8 @@ EXPORTED_SYMBOLS = (
     "salve_last_error",
     "salve_bev_workspace_bytes",
     "salve_bev_render_batch",
+    "salve_bev_scatter",
+    "salve_bev_densify",
     "salve_bev_export_u8",
     "salve_bev_tiles",
     "salve_resnet_create",
@@ -81,6 +83,10 @@ def load() -> ctypes.CDLL:
     lib.salve_bev_workspace_bytes.restype = sz
     lib.salve_bev_render_batch.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.salve_bev_render_batch.restype = ctypes.c_int
+    lib.salve_bev_scatter.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, sz, vp]
+    lib.salve_bev_scatter.restype = ctypes.c_int
+    lib.salve_bev_densify.argtypes = [ctypes.POINTER(BevConfig), i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.salve_bev_densify.restype = ctypes.c_int
     lib.salve_bev_export_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.salve_bev_export_u8.restype = ctypes.c_int
     lib.salve_bev_tiles.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]

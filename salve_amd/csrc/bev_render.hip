@@ -448,15 +448,17 @@ size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n) {
     return (size_t)n * npx * (sizeof(unsigned long long) + sizeof(uint32_t)) + 256;
 }
 
-int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth,
-                           int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n,
-                           uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
-                           int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream) {
+static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* pano_rgb, const uint16_t* pano_depth,
+                     int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, uint32_t* out_bev,
+                     int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask, int32_t* dbg_stats, void* workspace,
+                     size_t workspace_bytes, void* stream) {
     DevCfg d;
     if (!make_devcfg(cfg, &d)) return SALVE_ERR_BAD_ARG;
     if (n == 0) return SALVE_OK;
-    if (n < 0 || n_panos <= 0 || !pano_rgb || !pano_depth || !sphere || !hyps || !out_bev || !workspace) {
-        salve_fail("salve_bev_render_batch: null pointer or bad count");
+    const bool scatter = stages & 1, densify = stages & 2;
+    if (n < 0 || !workspace || (scatter && (n_panos <= 0 || !pano_rgb || !pano_depth || !sphere || !hyps)) ||
+        (densify && !out_bev)) {
+        salve_fail("salve_bev_*: null pointer or bad count");
         return SALVE_ERR_BAD_ARG;
     }
     if (n > 65535) { salve_fail("at most 65535 renders per call"); return SALVE_ERR_BAD_ARG; }
@@ -469,24 +471,48 @@ int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rg
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     uint32_t* sitelist = reinterpret_cast<uint32_t*>(keys + (size_t)n * npx);
 
-    SALVE_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)n * npx * sizeof(unsigned long long), s));
-    const int pts_per_block = SCATTER_THREADS * PTS_PER_THREAD;
-    dim3 g1((d.npts + pts_per_block - 1) / pts_per_block, n);
-    hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, keys,
-                       dbg_img_xy);
-    SALVE_HIP_CHECK(hipGetLastError());
-    static bool attr_set = false;
-    if (!attr_set) {
-        SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    if (scatter) {
+        SALVE_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)n * npx * sizeof(unsigned long long), s));
+        const int pts_per_block = SCATTER_THREADS * PTS_PER_THREAD;
+        dim3 g1((d.npts + pts_per_block - 1) / pts_per_block, n);
+        hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, keys,
+                           dbg_img_xy);
+        SALVE_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, keys, out_bev, sitelist, dbg_mask,
-                       dbg_stats);
-    SALVE_HIP_CHECK(hipGetLastError());
-    if (dbg_keys) SALVE_HIP_CHECK(hipMemcpyAsync(dbg_keys, keys, (size_t)n * npx * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
-    (void)n_panos;
+    if (densify) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, keys, out_bev, sitelist, dbg_mask,
+                           dbg_stats);
+        SALVE_HIP_CHECK(hipGetLastError());
+        if (dbg_keys) SALVE_HIP_CHECK(hipMemcpyAsync(dbg_keys, keys, (size_t)n * npx * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    }
     return SALVE_OK;
+}
+
+int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth,
+                           int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n,
+                           uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
+                           int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream) {
+    return bev_stage(cfg, 3, pano_rgb, pano_depth, n_panos, sphere, hyps, n, out_bev, dbg_img_xy, dbg_keys, dbg_mask, dbg_stats,
+                     workspace, workspace_bytes, stream);
+}
+
+int salve_bev_scatter(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth, int32_t n_panos,
+                      const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, int16_t* dbg_img_xy, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    return bev_stage(cfg, 1, pano_rgb, pano_depth, n_panos, sphere, hyps, n, nullptr, dbg_img_xy, nullptr, nullptr, nullptr,
+                     workspace, workspace_bytes, stream);
+}
+
+int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, uint64_t* dbg_keys, uint8_t* dbg_mask,
+                      int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream) {
+    return bev_stage(cfg, 2, nullptr, nullptr, 0, nullptr, nullptr, n, out_bev, nullptr, dbg_keys, dbg_mask, dbg_stats,
+                     workspace, workspace_bytes, stream);
 }
 
 int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream) {

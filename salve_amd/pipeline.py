@@ -1,0 +1,137 @@
+"""Fused render -> verify pipeline: alignment hypotheses in, verifier logits out, no JPEG hop.
+
+This is the MI355X counterpart of running the reference's two drivers back to back --
+scripts/render_dataset_bev.py:91-117 (one `generate_texture_maps_for_pair` per hypothesis x surface) and
+scripts/test.py:155-277 (DataLoader -> model -> softmax) -- with the tiles handed from the rasteriser to the
+verifier in HBM instead of through JPEG files (bev_rendering_utils.py:629-630 -> zind_data.py:306-315).
+
+Work decomposition per hypothesis (i1, i2, i2Ti1) and surface:
+  * pano i1 is rendered under the pose (hypothesis dependent)          -> one render per hypothesis x surface;
+  * pano i2 is rendered at identity (bev_rendering_utils.py:455), which does not depend on the hypothesis, so
+    its BEV image is rendered once per (pano, surface) and cached on the device.
+Channel order of the early-fusion input follows zind_data.py:306-315: single surface (img1, img2); two surfaces
+(ceiling1, ceiling2, floor1, floor2).
+
+Multi-GPU: hypotheses are independent, so each rank takes a contiguous block of the table, holds all panoramas and
+a full weight replica, and the logits are collected with ONE all-gather (RCCL) -- SURVEY.md section 8e.
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from salve_amd import _lib
+from salve_amd.rasteriser import SURFACES, BevRasteriser, pack_hypotheses
+from salve_amd.synthetic import HypothesisTable
+
+MODALITY_SURFACES = {
+    ("floor_rgb_texture",): ["floor"],
+    ("ceiling_rgb_texture",): ["ceiling"],
+    ("ceiling_rgb_texture", "floor_rgb_texture"): ["ceiling", "floor"],
+}
+
+
+def surfaces_for(modalities: Sequence[str]) -> List[str]:
+    key = tuple(sorted(modalities))
+    if key not in MODALITY_SURFACES:
+        raise RuntimeError(f"Unsupported modalities for the fused render+verify path: {modalities}")
+    return MODALITY_SURFACES[key]
+
+
+class RenderVerifyPipeline:
+    def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: int = 256) -> None:
+        self.device = torch.device(device)
+        self.model = model
+        self.surfaces = surfaces_for(model.modalities)
+        self.engine = model.compiled(self.device)
+        self.ras = BevRasteriser(self.device, pano_hw=pano_hw)
+        self.chunk = chunk
+        S = len(self.surfaces)
+        Hb, Wb = self.ras.bev_hw
+        self.bev = torch.empty((chunk * S, Hb, Wb), dtype=torch.int32, device=self.device)
+        # tiles: bf16 NHWC, pad channels (never written) stay zero
+        self.tiles = torch.zeros((chunk, self.ras.crop, self.ras.crop, self.engine.in_channels), dtype=torch.bfloat16,
+                                 device=self.device)
+        self.pano_rgb = self.pano_depth = self.ref_bev = None
+        self.n_panos = 0
+
+    # ------------------------------------------------------------------ panoramas
+    def load_panos(self, rgb: np.ndarray, depth: np.ndarray) -> None:
+        """Upload P panoramas and render their hypothesis-independent (identity) BEV images once."""
+        self.pano_rgb, self.pano_depth = self.ras.upload_panos(rgb, depth)
+        P = self.n_panos = int(rgb.shape[0])
+        S = len(self.surfaces)
+        idx = np.repeat(np.arange(P), S)
+        surf = np.tile([SURFACES[s] for s in self.surfaces], P)
+        h = pack_hypotheses(idx, surf, np.tile(np.eye(2, dtype=np.float32), (P * S, 1, 1)), np.zeros((P * S, 2), np.float32),
+                            np.zeros(P * S))
+        Hb, Wb = self.ras.bev_hw
+        self.ref_bev = torch.empty((P * S, Hb, Wb), dtype=torch.int32, device=self.device)
+        hd = self.ras.upload_hypotheses(h)
+        for lo in range(0, P * S, 256):
+            n = min(256, P * S - lo)
+            self.ras.render(self.pano_rgb, self.pano_depth, hd[lo * _lib.HYP_DTYPE.itemsize:], n, out_bev=self.ref_bev[lo:lo + n])
+
+    # ------------------------------------------------------------------ hypotheses
+    def prepare(self, hyp: HypothesisTable):
+        """Upload the render table and the tile job tables of a hypothesis shard (once, outside the timed loop)."""
+        N, S = len(hyp), len(self.surfaces)
+        surf_ids = [SURFACES[s] for s in self.surfaces]
+        rows = pack_hypotheses(np.repeat(hyp.i1, S), np.tile(surf_ids, N), np.repeat(hyp.R, S, axis=0), np.repeat(hyp.t, S, axis=0),
+                               np.ones(N * S))
+        j = np.arange(N)
+        slot = j % self.chunk
+        jobs1_bev, jobs1_slot, jobs1_chan = [], [], []
+        jobs2_bev, jobs2_slot, jobs2_chan = [], [], []
+        for si in range(S):
+            jobs1_bev.append(slot * S + si)           # render output of this chunk
+            jobs1_slot.append(slot)
+            jobs1_chan.append(np.full(N, 6 * si))
+            jobs2_bev.append(hyp.i2.astype(np.int64) * S + si)  # cached identity render of pano i2
+            jobs2_slot.append(slot)
+            jobs2_chan.append(np.full(N, 6 * si + 3))
+        # job tables are stored hypothesis-major so that a chunk is a contiguous slice
+        st = lambda parts: np.stack(parts, 1).reshape(-1)
+        return {
+            "n": N,
+            "rows": self.ras.upload_hypotheses(rows),
+            "jobs1": self.ras.upload_tile_jobs(st(jobs1_bev), st(jobs1_slot), st(jobs1_chan)),
+            "jobs2": self.ras.upload_tile_jobs(st(jobs2_bev), st(jobs2_slot), st(jobs2_chan)),
+        }
+
+    def score(self, prepared, out: Optional[torch.Tensor] = None, timers=None) -> torch.Tensor:
+        """Render + verify every hypothesis of a prepared shard.  Returns fp32 logits [N, num_classes]."""
+        N, S = prepared["n"], len(self.surfaces)
+        if out is None:
+            out = torch.empty((N, self.engine.num_classes), dtype=torch.float32, device=self.device)
+        hb, jb = _lib.HYP_DTYPE.itemsize, _lib.TILE_JOB_DTYPE.itemsize
+        for lo in range(0, N, self.chunk):
+            n = min(self.chunk, N - lo)
+            rows = prepared["rows"][lo * S * hb:]
+            if timers is not None:
+                self.ras.scatter(self.pano_rgb, self.pano_depth, rows, n * S)
+                timers[0].record()
+                self.ras.densify(n * S, self.bev)
+                timers[1].record()
+                timers = None  # time the first chunk only
+            else:
+                self.ras.render(self.pano_rgb, self.pano_depth, rows, n * S, out_bev=self.bev)
+            self.ras.tiles(self.bev, prepared["jobs1"][lo * S * jb:], n * S, self.tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
+            self.ras.tiles(self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, self.tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
+            self.engine.forward_nhwc(self.tiles[:n], out=out[lo:lo + n])
+        return out
+
+
+def gather_logits(local: torch.Tensor, world: int) -> torch.Tensor:
+    """The path's only collective: one all-gather of the [N/G, C] fp32 logits (mirrors DataParallel's gather of
+    the model outputs, reference train_utils.py:214-215)."""
+    if world == 1:
+        return local
+    import torch.distributed as dist
+
+    out = torch.empty((world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out

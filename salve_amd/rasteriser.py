@@ -160,6 +160,23 @@ class BevRasteriser:
         _lib.check(st, "salve_bev_render_batch")
         return out_bev, dbg
 
+    def scatter(self, pano_rgb: torch.Tensor, pano_depth: torch.Tensor, hyps_dev: torch.Tensor, n: int) -> None:
+        """First half of `render`: z-order key images into the workspace."""
+        ws = self._workspace(n)
+        st = self.lib.salve_bev_scatter(
+            ctypes.byref(self.cfg), ctypes.c_void_p(pano_rgb.data_ptr()), ctypes.c_void_p(pano_depth.data_ptr()),
+            int(pano_rgb.shape[0]), ctypes.c_void_p(self.sphere.data_ptr()), ctypes.c_void_p(hyps_dev.data_ptr()), n, None,
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        _lib.check(st, "salve_bev_scatter")
+
+    def densify(self, n: int, out_bev: torch.Tensor) -> torch.Tensor:
+        """Second half of `render`: key images -> BEV images."""
+        ws = self._workspace(n)
+        st = self.lib.salve_bev_densify(ctypes.byref(self.cfg), n, ctypes.c_void_p(out_bev.data_ptr()), None, None, None,
+                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        _lib.check(st, "salve_bev_densify")
+        return out_bev
+
     def export_u8(self, bev: torch.Tensor) -> torch.Tensor:
         """int32 [n,H,W] -> uint8 [n,H,W,3] (the array `render_bev_image` returns)."""
         n, Hb, Wb = bev.shape
