@@ -57,7 +57,7 @@ typedef struct {
     int32_t bev_h, bev_w;       /* BEVParams.img_h + 1, img_w + 1 (:292-293); 501, 501 */
     int32_t mask_k;             /* box-filter size of remove_hallucinated_content; 11 */
     float depth_scale;          /* uint16 depth -> metres, applied in float32 (:367); 0.001f */
-    int32_t reserved0;
+    int32_t out_flags;          /* 0 for render_bev_image; 1: no vertical flip, 2: no mask (plain interpolation) */
     double win_xmin, win_xmax, win_ymin, win_ymax; /* prune_to_2d_bbox window, inclusive (:38-45); -5, 5, -5, 5 */
     double img_tx, img_ty, img_scale; /* bevimg_Sim2_world: (p + t) * s (bevparams.py:69-78); 5, 5, 50 */
     double rot_pre[4];          /* rotmat2d(-90), row-major float64 exactly as numpy computes it (:443) */
@@ -94,12 +94,14 @@ size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n);
  *   dbg_keys    device uint64 [n, bev_h*bev_w] or NULL: z-order winner per pixel (unflipped):
  *               0 = empty, else ((slice+1) << 45) | (point_index << 24) | 0xBBGGRR
  *   dbg_mask    device uint8 [n, bev_h, bev_w] or NULL: hallucination mask (unflipped)
- *   dbg_stats   device int32 [n, 8] or NULL: {n_sites, wrap_steps, error_flag, ...}
+ *   dbg_stats   device int32 [n, 8] or NULL: {n_sites, min x, max x, occupied rows, walk iterations, error flag,
+ *               sites handed to the general walk, queued triangles}
+ *   out_in_window device int32 [n] or NULL: points inside the window per render (0 => the reference returns None, :279)
  */
 int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth,
                            int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n,
                            uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
-                           int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream);
+                           int32_t* dbg_stats, int32_t* out_in_window, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The two halves of salve_bev_render_batch as separate launches (same arguments, same workspace):
  * salve_bev_scatter fills the z-order key images, salve_bev_densify turns them into BEV images.  Used by the
@@ -109,6 +111,13 @@ int salve_bev_scatter(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, co
                       size_t workspace_bytes, void* stream);
 int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, uint64_t* dbg_keys, uint8_t* dbg_mask,
                       int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Splat an explicit coloured point cloud -- the `xyzrgb` argument of render_bev_image (bev_rendering_utils.py:254-308):
+ * xyz device double [n_points, 3] in the world frame, rgb device uint8 [n_points, 3] (the reference's float colours
+ * already truncated to uint8, :307-308).  Fills key image 0 of the workspace; follow with salve_bev_densify(cfg, 1, ...).
+ * n_in_window (device int32) receives the number of points inside the window (0 => render_bev_image returns None, :279). */
+int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, const uint8_t* rgb, int32_t n_points,
+                             int32_t* n_in_window, void* workspace, size_t workspace_bytes, void* stream);
 
 /* BEV uint32 -> uint8 [n, bev_h, bev_w, 3], the array render_bev_image returns (bev_rendering_utils.py:328). */
 int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream);

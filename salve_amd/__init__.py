@@ -7,3 +7,16 @@ behind the C ABI declared in ``include/salve_hip.h``.
 """
 
 __version__ = "0.1.0"
+
+
+def install_as_salve() -> None:
+    """Alias this package as `salve` so that `import salve.utils.bev_rendering_utils`, `salve.models.early_fusion`,
+    `salve.common.sim2` ... in the reference's scripts resolve to the MI355X implementation."""
+    import importlib
+    import sys
+
+    sys.modules.setdefault("salve", sys.modules[__name__])
+    for name in ("utils", "common", "models", "utils.bev_rendering_utils", "utils.hohonet_pano_utils", "utils.rotation_utils",
+                 "utils.normalization_utils", "utils.mesh_grid", "common.sim2", "common.bevparams", "models.early_fusion",
+                 "models.resnet_factory", "train_utils", "training_config"):
+        sys.modules.setdefault(f"salve.{name}", importlib.import_module(f"salve_amd.{name}"))

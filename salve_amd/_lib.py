@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "salve_bev_render_batch",
     "salve_bev_scatter",
     "salve_bev_densify",
+    "salve_bev_scatter_points",
     "salve_bev_export_u8",
     "salve_bev_tiles",
     "salve_resnet_create",
@@ -41,7 +42,7 @@ class BevConfig(ctypes.Structure):
     _fields_ = [
         ("pano_h", ctypes.c_int32), ("pano_w", ctypes.c_int32), ("crop_rows", ctypes.c_int32),
         ("bev_h", ctypes.c_int32), ("bev_w", ctypes.c_int32), ("mask_k", ctypes.c_int32),
-        ("depth_scale", ctypes.c_float), ("reserved0", ctypes.c_int32),
+        ("depth_scale", ctypes.c_float), ("out_flags", ctypes.c_int32),
         ("win_xmin", ctypes.c_double), ("win_xmax", ctypes.c_double),
         ("win_ymin", ctypes.c_double), ("win_ymax", ctypes.c_double),
         ("img_tx", ctypes.c_double), ("img_ty", ctypes.c_double), ("img_scale", ctypes.c_double),
@@ -81,12 +82,14 @@ def load() -> ctypes.CDLL:
     lib.salve_last_error.restype = ctypes.c_char_p
     lib.salve_bev_workspace_bytes.argtypes = [ctypes.POINTER(BevConfig), i32]
     lib.salve_bev_workspace_bytes.restype = sz
-    lib.salve_bev_render_batch.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.salve_bev_render_batch.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.salve_bev_render_batch.restype = ctypes.c_int
     lib.salve_bev_scatter.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, sz, vp]
     lib.salve_bev_scatter.restype = ctypes.c_int
     lib.salve_bev_densify.argtypes = [ctypes.POINTER(BevConfig), i32, vp, vp, vp, vp, vp, sz, vp]
     lib.salve_bev_densify.restype = ctypes.c_int
+    lib.salve_bev_scatter_points.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, sz, vp]
+    lib.salve_bev_scatter_points.restype = ctypes.c_int
     lib.salve_bev_export_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.salve_bev_export_u8.restype = ctypes.c_int
     lib.salve_bev_tiles.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]

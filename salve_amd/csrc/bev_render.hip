@@ -24,6 +24,7 @@
 
 #include "../../include/salve_hip.h"
 #include "star_delaunay.h"
+#include "star_local.h"
 #include "salve_common.h"
 
 namespace {
@@ -42,13 +43,15 @@ struct DevCfg {
     double rp00, rp01, rp10, rp11;
     double zlo[2], zhi[2], zmin;
     int nslices;
+    int out_flags;  // 1: do not flip the image vertically, 2: no hallucination mask (plain interpolation)
     int dbg_flags;  // development only: 1 = skip the star phase, 2 = walk stars but do not rasterise
 };
 
 // ------------------------------------------------------------------------------------------------ scatter
 __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
     DevCfg c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, const double* __restrict__ sphere,
-    const salve_bev_hyp_t* __restrict__ hyps, unsigned long long* __restrict__ keys, int16_t* __restrict__ dbg_xy) {
+    const salve_bev_hyp_t* __restrict__ hyps, unsigned long long* __restrict__ keys, int16_t* __restrict__ dbg_xy,
+    int32_t* __restrict__ in_window) {
     const int rid = blockIdx.y;
     const salve_bev_hyp_t h = hyps[rid];
     const int p0 = (blockIdx.x * SCATTER_THREADS + threadIdx.x) * PTS_PER_THREAD;  // first point (cropped raster)
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
                 const double fy = rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
                 ix = (int)fx;
                 iy = (int)fy;
+                if (in_window) atomicAdd(in_window + rid, 1);
                 const double zs = floor(z) - c.zmin;  // unit slices from an integer z_min: exact
                 if (zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H) {
                     const unsigned long long key = ((unsigned long long)((int)zs + 1) << 45) |
@@ -116,13 +120,33 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
     }
 }
 
+// Same splat for an explicit coloured point cloud (the `xyzrgb` argument of render_bev_image): world-frame points,
+// no back-projection and no pose; prune -> pixel index -> z-order key.  The point's position in the list is its index.
+__global__ __launch_bounds__(256) void bev_scatter_points_kernel(DevCfg c, const double* __restrict__ xyz,
+                                                                 const uint8_t* __restrict__ rgb, int npts,
+                                                                 unsigned long long* __restrict__ kimg,
+                                                                 int* __restrict__ n_in_window) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npts) return;
+    const double x1 = xyz[3 * (size_t)i], y1 = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    if (!(c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax)) return;
+    atomicAdd(n_in_window, 1);
+    const int ix = (int)rint((fma(y1, 0.0, x1 * 1.0) + c.tx) * c.scale);
+    const int iy = (int)rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
+    const double zs = floor(z) - c.zmin;
+    if (!(zs >= 0.0 && zs < (double)c.nslices) || ix < 0 || ix >= c.W || iy < 0 || iy >= c.H) return;
+    const uint32_t col = (uint32_t)rgb[3 * (size_t)i] | ((uint32_t)rgb[3 * (size_t)i + 1] << 8) | ((uint32_t)rgb[3 * (size_t)i + 2] << 16);
+    atomicMax(kimg + (size_t)iy * c.W + ix, ((unsigned long long)((int)zs + 1) << 45) | ((unsigned long long)i << 24) | col);
+}
+
 // ------------------------------------------------------------------------------------------------ densify
 struct RasterEmit {
     int H, W, wpr;
     const uint32_t* occ;
     const uint32_t* msk;
     const unsigned long long* keys;
-    uint32_t* bev;  // flipped output image of this render
+    uint32_t* bev;  // output image of this render
+    int flip;       // H - 1 to flip vertically (np.flipud), else 0 with sign handled below
     bool skip;
 
     __device__ __forceinline__ uint32_t blend(int32_t wa, int32_t wb, int32_t wc, int32_t area, uint32_t ca,
@@ -192,9 +216,28 @@ struct RasterEmit {
                         cc = (uint32_t)keys[(size_t)cy * W + cx] & 0xFFFFFFu;
                         have = true;
                     }
-                    bev[(size_t)(H - 1 - y) * W + x] = blend(wa, wb, wc, area, ca, cb, cc);
+                    bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = blend(wa, wb, wc, area, ca, cb, cc);
                 }
             }
+        }
+    }
+};
+
+// Emit functor of the local star walk: owned triangles go to a per-render queue (8 bytes each: the site, and the two
+// other vertices relative to it) and are rasterised afterwards by all lanes at once.
+struct QueueEmit {
+    unsigned long long* queue;
+    int* counter;  // LDS
+    int capacity;
+    RasterEmit fallback;
+    __device__ __forceinline__ void operator()(int ax, int ay, int bx, int by, int cx, int cy) const {
+        const int slot = atomicAdd(counter, 1);
+        if (slot < capacity) {
+            const uint32_t rel = (uint32_t)((bx - ax) & 0xFF) | ((uint32_t)((by - ay) & 0xFF) << 8) |
+                                 ((uint32_t)((cx - ax) & 0xFF) << 16) | ((uint32_t)((cy - ay) & 0xFF) << 24);
+            queue[slot] = ((unsigned long long)rel << 32) | ((uint32_t)ay << 16) | (uint32_t)ax;
+        } else {
+            fallback(ax, ay, bx, by, cx, cy);  // queue full (cannot happen below ~50 % occupancy): rasterise in place
         }
     }
 };
@@ -206,7 +249,8 @@ __device__ __forceinline__ unsigned long long load_key(const unsigned long long*
 
 __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     DevCfg c, const unsigned long long* __restrict__ keys_all, uint32_t* __restrict__ bev_all,
-    uint32_t* __restrict__ sitelist_all, uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats) {
+    uint32_t* __restrict__ sitelist_all, uint32_t* __restrict__ hardlist_all, unsigned long long* __restrict__ triq_all,
+    uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = c.H, W = c.W, wpr = c.wpr;
     uint32_t* occ = reinterpret_cast<uint32_t*>(smem);
@@ -220,10 +264,12 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     const unsigned long long* keys = keys_all + (size_t)rid * H * W;
     uint32_t* bev = bev_all + (size_t)rid * H * W;
     uint32_t* sitelist = sitelist_all + (size_t)rid * H * W;
+    uint32_t* hardlist = hardlist_all + (size_t)rid * H * W;
+    unsigned long long* triq = triq_all + (size_t)rid * H * W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = DENSIFY_THREADS >> 6;
     const int p = c.mask_half;
 
-    if (tid < 8) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : 0);
+    if (tid < 12) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : 0);  // [6] site cursor [7] hard sites [8] queued triangles
     __syncthreads();
 
     // ---- phase B: bitmaps by wave ballot (no LDS atomics), row extents, compact site list.
@@ -312,6 +358,10 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     }
     __syncthreads();
 
+    if (c.out_flags & 2) {
+        for (int i = tid; i < H * wpr; i += DENSIFY_THREADS) msk[i] = 0xFFFFFFFFu;
+        __syncthreads();
+    }
     const int nsites = scal[0];
     // interp_dense_grid_from_sparse early-outs (interpolation_utils.py:39-43): < 4 points, all x equal, all y equal
     const bool degenerate = nsites < 4 || scal[1] == scal[2] || scal[3] <= 1;
@@ -325,7 +375,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
             const bool m = (mw >> (x & 31)) & 1u;
             uint32_t val = 0;
             if (!degenerate && m && ((ow >> (x & 31)) & 1u)) val = (uint32_t)load_key(keys + (size_t)y * W + x) & 0xFFFFFFu;
-            bev[(size_t)(H - 1 - y) * W + x] = val;
+            bev[(size_t)((c.out_flags & 1) ? y : H - 1 - y) * W + x] = val;
             if (dbg_mask) dbg_mask[((size_t)rid * H + y) * W + x] = m ? 1 : 0;
         }
     }
@@ -334,24 +384,55 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
-    // ---- phase E: Delaunay stars + rasterisation of owned triangles.
+    // ---- phase E: Delaunay stars.
+    //      E1: every lane runs the local state machine (star_local.h) and pulls sites from a shared cursor, so lanes
+    //          never idle; owned triangles are queued; sites whose star does not fit the window go to the hard list.
+    //      E2: hard sites (hull, sparse regions: a few %) walk their star with the general algorithm and rasterise
+    //          in place.   F: all lanes rasterise the queued triangles.
     if (!degenerate && !(c.dbg_flags & 1)) {
         SdGrid g = {H, W, wpr, occ, rmin, rmax};
-        RasterEmit emit = {H, W, wpr, occ, msk, keys, bev, (c.dbg_flags & 2) != 0};
-        int steps = 0, err = 0;
-        for (int i = tid; i < nsites; i += DENSIFY_THREADS) {
-            const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int r = sd_star(g, (int)(s & 0xFFFFu), (int)(s >> 16), emit);
-            if (r < 0) err = 1; else steps += r;
+        RasterEmit raster = {H, W, wpr, occ, msk, keys, bev, (c.out_flags & 1) ? -1 : H - 1, (c.dbg_flags & 2) != 0};
+        QueueEmit qemit = {triq, &scal[8], H * W, raster};
+        SdLocal st;
+        bool active = false;
+        int iters = 0;
+        for (;;) {
+            if (!active) {
+                const int i = atomicAdd(&scal[6], 1);
+                if (i >= nsites) break;
+                const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sdl_begin(st, g, (int)(s & 0xFFFFu), (int)(s >> 16));
+                active = true;
+            }
+            const int r = sdl_iter(st, qemit);
+            iters++;
+            if (r != SDL_CONTINUE) {
+                active = false;
+                if (r == SDL_SITE_HARD) hardlist[atomicAdd(&scal[7], 1)] = ((uint32_t)st.sy << 16) | (uint32_t)st.sx;
+            }
         }
-        if (dbg_stats) {
-            atomicAdd(&scal[4], steps);
-            if (err) atomicOr(&scal[5], 1);
+        if (dbg_stats) atomicAdd(&scal[4], iters);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        const int nhard = scal[7];
+        const int nq = min(scal[8], H * W);
+        int err = 0;
+        for (int i = tid; i < ((c.dbg_flags & 4) ? 0 : nhard); i += DENSIFY_THREADS) {
+            const uint32_t s = __hip_atomic_load(hardlist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sd_star(g, (int)(s & 0xFFFFu), (int)(s >> 16), raster) < 0) err = 1;
+        }
+        if (err) atomicOr(&scal[5], 1);
+        for (int i = tid; i < ((c.dbg_flags & 8) ? 0 : nq); i += DENSIFY_THREADS) {
+            const unsigned long long e = __hip_atomic_load(triq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ax = (int)(e & 0xFFFFu), ay = (int)((e >> 16) & 0xFFFFu);
+            const uint32_t rel = (uint32_t)(e >> 32);
+            raster(ax, ay, ax + (int8_t)(rel & 0xFF), ay + (int8_t)((rel >> 8) & 0xFF), ax + (int8_t)((rel >> 16) & 0xFF),
+                   ay + (int8_t)(rel >> 24));
         }
     }
     if (dbg_stats) {
         __syncthreads();
-        if (tid < 8) dbg_stats[rid * 8 + tid] = tid < 6 ? scal[tid] : 0;
+        if (tid < 8) dbg_stats[rid * 8 + tid] = tid < 6 ? scal[tid] : scal[tid + 1];  // [6] hard sites [7] queued triangles
     }
 }
 
@@ -427,7 +508,7 @@ bool make_devcfg(const salve_bev_config_t* cfg, DevCfg* d) {
     d->tx = cfg->img_tx; d->ty = cfg->img_ty; d->scale = cfg->img_scale;
     d->rp00 = cfg->rot_pre[0]; d->rp01 = cfg->rot_pre[1]; d->rp10 = cfg->rot_pre[2]; d->rp11 = cfg->rot_pre[3];
     for (int i = 0; i < 2; i++) { d->zlo[i] = cfg->z_lo[i]; d->zhi[i] = cfg->z_hi[i]; }
-    d->zmin = cfg->z_min; d->nslices = cfg->n_slices; d->dbg_flags = cfg->reserved1;
+    d->zmin = cfg->z_min; d->nslices = cfg->n_slices; d->dbg_flags = cfg->reserved1; d->out_flags = cfg->out_flags;
     const int ntasks = ((d->H + MASK_ROWS_PER_TASK - 1) / MASK_ROWS_PER_TASK) * d->wpr;
     if (ntasks > DENSIFY_THREADS) return salve_fail("bev image too large for the LDS mask pass");
     return true;
@@ -445,13 +526,13 @@ size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n) {
     DevCfg d;
     if (n <= 0 || !make_devcfg(cfg, &d)) return 0;
     const size_t npx = (size_t)d.H * d.W;
-    return (size_t)n * npx * (sizeof(unsigned long long) + sizeof(uint32_t)) + 256;
+    return (size_t)n * npx * (2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t)) + 256;
 }
 
 static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* pano_rgb, const uint16_t* pano_depth,
                      int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, uint32_t* out_bev,
-                     int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask, int32_t* dbg_stats, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+                     int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask, int32_t* dbg_stats, int32_t* in_window,
+                     void* workspace, size_t workspace_bytes, void* stream) {
     DevCfg d;
     if (!make_devcfg(cfg, &d)) return SALVE_ERR_BAD_ARG;
     if (n == 0) return SALVE_OK;
@@ -469,14 +550,17 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
     hipStream_t s = (hipStream_t)stream;
     const size_t npx = (size_t)d.H * d.W;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    uint32_t* sitelist = reinterpret_cast<uint32_t*>(keys + (size_t)n * npx);
+    unsigned long long* triq = keys + (size_t)n * npx;
+    uint32_t* sitelist = reinterpret_cast<uint32_t*>(triq + (size_t)n * npx);
+    uint32_t* hardlist = sitelist + (size_t)n * npx;
 
     if (scatter) {
         SALVE_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)n * npx * sizeof(unsigned long long), s));
         const int pts_per_block = SCATTER_THREADS * PTS_PER_THREAD;
         dim3 g1((d.npts + pts_per_block - 1) / pts_per_block, n);
+        if (in_window) SALVE_HIP_CHECK(hipMemsetAsync(in_window, 0, (size_t)n * sizeof(int32_t), s));
         hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, keys,
-                           dbg_img_xy);
+                           dbg_img_xy, in_window);
         SALVE_HIP_CHECK(hipGetLastError());
     }
     if (densify) {
@@ -486,8 +570,8 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, keys, out_bev, sitelist, dbg_mask,
-                           dbg_stats);
+        hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, keys, out_bev, sitelist, hardlist, triq,
+                           dbg_mask, dbg_stats);
         SALVE_HIP_CHECK(hipGetLastError());
         if (dbg_keys) SALVE_HIP_CHECK(hipMemcpyAsync(dbg_keys, keys, (size_t)n * npx * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     }
@@ -497,22 +581,44 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
 int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth,
                            int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n,
                            uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
-                           int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream) {
+                           int32_t* dbg_stats, int32_t* out_in_window, void* workspace, size_t workspace_bytes, void* stream) {
     return bev_stage(cfg, 3, pano_rgb, pano_depth, n_panos, sphere, hyps, n, out_bev, dbg_img_xy, dbg_keys, dbg_mask, dbg_stats,
-                     workspace, workspace_bytes, stream);
+                     out_in_window, workspace, workspace_bytes, stream);
 }
 
 int salve_bev_scatter(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth, int32_t n_panos,
                       const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, int16_t* dbg_img_xy, void* workspace,
                       size_t workspace_bytes, void* stream) {
     return bev_stage(cfg, 1, pano_rgb, pano_depth, n_panos, sphere, hyps, n, nullptr, dbg_img_xy, nullptr, nullptr, nullptr,
-                     workspace, workspace_bytes, stream);
+                     nullptr, workspace, workspace_bytes, stream);
 }
 
 int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, uint64_t* dbg_keys, uint8_t* dbg_mask,
                       int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream) {
     return bev_stage(cfg, 2, nullptr, nullptr, 0, nullptr, nullptr, n, out_bev, nullptr, dbg_keys, dbg_mask, dbg_stats,
-                     workspace, workspace_bytes, stream);
+                     nullptr, workspace, workspace_bytes, stream);
+}
+
+int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, const uint8_t* rgb, int32_t n_points,
+                             int32_t* n_in_window, void* workspace, size_t workspace_bytes, void* stream) {
+    DevCfg d;
+    if (!make_devcfg(cfg, &d)) return SALVE_ERR_BAD_ARG;
+    if (n_points < 0 || !workspace || !n_in_window || (n_points > 0 && (!xyz || !rgb))) {
+        salve_fail("salve_bev_scatter_points: null pointer or bad count");
+        return SALVE_ERR_BAD_ARG;
+    }
+    if ((long long)n_points >= (1ll << 21)) { salve_fail("at most 2^21 - 1 points"); return SALVE_ERR_UNSUPPORTED; }
+    if (workspace_bytes < salve_bev_workspace_bytes(cfg, 1)) { salve_fail("workspace too small"); return SALVE_ERR_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    SALVE_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)d.H * d.W * sizeof(unsigned long long), s));
+    SALVE_HIP_CHECK(hipMemsetAsync(n_in_window, 0, sizeof(int32_t), s));
+    if (n_points > 0) {
+        hipLaunchKernelGGL(bev_scatter_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, d, xyz, rgb, n_points, keys,
+                           n_in_window);
+        SALVE_HIP_CHECK(hipGetLastError());
+    }
+    return SALVE_OK;
 }
 
 int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream) {

@@ -1,0 +1,263 @@
+// star_local.h -- the Delaunay star walk of star_delaunay.h as a per-lane STATE MACHINE over a register-resident
+// 32 x 15 pixel window, written for SIMT execution on 64-wide wavefronts.
+//
+// Why: with one site per lane and the textbook nested loops (steps -> rows -> words -> bits) a wavefront pays, at
+// every nesting level, for its slowest lane; measured lane utilisation of that form was 15 %.  Here every lane
+// runs ONE flat loop whose iteration is either "advance to the next window row" or "test one candidate"; a lane
+// that finishes a site immediately pulls the next one, so lanes never wait for each other and the only cost of
+// divergence is that both (short) bodies are issued.
+//
+// Exactness: inside the window all coordinates are relative to the site and bounded by 16, so the orientation and
+// in-circle determinants are integers below 2^24 and are evaluated EXACTLY in float32 (full-rate VALU).  A query is
+// accepted only if its final circle lies inside the window (then every site that could matter was examined with the
+// exact predicates); otherwise the whole site is handed to the general algorithm (sd_star), as are hull sites.
+// The symbolic perturbation (raster order of the sites) is the one of star_delaunay.h.
+#pragma once
+#include "star_delaunay.h"
+
+#define SDL_ROWS 15      // window rows: sy-7 .. sy+7
+#define SDL_HALF 7
+#define SDL_XLO (-16)    // window columns: sx-16 .. sx+15 (bit = dx + 16)
+#define SDL_XHI 15
+#define SDL_NONE 0x7FFF
+
+enum { SDL_CONTINUE = 0, SDL_SITE_DONE = 1, SDL_SITE_HARD = 2 };
+enum { SDL_MODE_NEAREST = 0, SDL_MODE_APEX = 1 };
+
+struct SdLocal {
+    int sx, sy;
+    uint32_t W[SDL_ROWS];
+    int n0x, n0y;      // first neighbour (relative)
+    int ax, ay;        // current edge s -> a (relative)
+    int px, py;        // best apex so far (px == SDL_NONE: none)
+    float ux, uy, r2;  // circle through s, a, p (relative to s); for MODE_NEAREST: centre s, r2 = best distance^2
+    int mode, k, m, row, deg, stage;
+    float hx, hy, hr2;  // stage 0 looks only inside this disc around the edge; a second sweep follows if that was not enough
+    uint32_t bits;
+    bool upDone, dnDone;
+};
+
+SD_FN uint32_t sdl_pick(const uint32_t* W, int r) {  // W[r] with r in 0..14, as a select tree (no scratch)
+    const uint32_t a0 = (r & 1) ? W[1] : W[0], a1 = (r & 1) ? W[3] : W[2], a2 = (r & 1) ? W[5] : W[4];
+    const uint32_t a3 = (r & 1) ? W[7] : W[6], a4 = (r & 1) ? W[9] : W[8], a5 = (r & 1) ? W[11] : W[10];
+    const uint32_t a6 = (r & 1) ? W[13] : W[12], a7 = W[14];
+    const uint32_t b0 = (r & 2) ? a1 : a0, b1 = (r & 2) ? a3 : a2, b2 = (r & 2) ? a5 : a4, b3 = (r & 2) ? a7 : a6;
+    const uint32_t c0 = (r & 4) ? b1 : b0, c1 = (r & 4) ? b3 : b2;
+    return (r & 8) ? c1 : c0;
+}
+
+// 32 bits of bitmap row y starting at column x0 (may be negative / beyond the image: zeros)
+SD_FN uint32_t sdl_row32(const SdGrid& g, int y, int x0) {
+    if (y < 0 || y >= g.H) return 0u;
+    const int w0 = x0 >> 5, sh = x0 & 31;  // arithmetic shift: floor
+    const uint32_t lo = (w0 >= 0 && w0 < g.wpr) ? g.occ[y * g.wpr + w0] : 0u;
+    const uint32_t hi = (w0 + 1 >= 0 && w0 + 1 < g.wpr) ? g.occ[y * g.wpr + w0 + 1] : 0u;
+    return sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+}
+
+SD_FN uint32_t sdl_range_mask(int xl, int xr) {  // bits for relative columns xl..xr, clipped to the window
+    if (xl < SDL_XLO) xl = SDL_XLO;
+    if (xr > SDL_XHI) xr = SDL_XHI;
+    if (xl > xr) return 0u;
+    const int lo = xl - SDL_XLO, hi = xr - SDL_XLO;
+    return (0xFFFFFFFFu << lo) & (0xFFFFFFFFu >> (31 - hi));
+}
+
+SD_FN void sdl_restart_scan(SdLocal& s) {
+    s.k = -1;
+    s.bits = 0;
+    s.upDone = s.dnDone = false;
+}
+
+SD_FN void sdl_start_query(SdLocal& s, int mode) {
+    s.mode = mode;
+    s.px = SDL_NONE;
+    s.py = 0;
+    s.stage = 0;
+    sdl_restart_scan(s);
+    if (mode == SDL_MODE_APEX) {
+        s.m = (s.ay + (s.ay >= 0 ? 1 : 0)) >> 1;  // a row next to the middle of the edge
+        s.hx = 0.5f * (float)s.ax;
+        s.hy = 0.5f * (float)s.ay;
+        const float hr = 0.5f * sqrtf((float)(s.ax * s.ax + s.ay * s.ay)) + 2.5f;
+        s.hr2 = hr * hr;
+    } else {
+        s.m = 0;
+        s.hx = s.hy = 0.f;
+        s.hr2 = 1e9f;
+        s.ux = s.uy = 0.f;
+        s.r2 = 1e9f;
+    }
+}
+
+SD_FN void sdl_begin(SdLocal& s, const SdGrid& g, int sx, int sy) {
+    s.sx = sx;
+    s.sy = sy;
+#pragma unroll
+    for (int r = 0; r < SDL_ROWS; r++) s.W[r] = sdl_row32(g, sy - SDL_HALF + r, sx + SDL_XLO);
+    s.W[SDL_HALF] &= ~(1u << (0 - SDL_XLO));  // the site itself is not a candidate
+    s.deg = 0;
+    s.ax = s.ay = 0;
+    // an 8-neighbour, if there is one, is a nearest site (distance 1 before sqrt 2) and needs no search
+    const uint32_t c = s.W[SDL_HALF], u = s.W[SDL_HALF + 1], d = s.W[SDL_HALF - 1];
+    const int o = 0 - SDL_XLO;
+    int nx = SDL_NONE, ny = 0;
+    if ((d >> (o + 1)) & 1u) { nx = 1; ny = -1; }
+    if ((d >> (o - 1)) & 1u) { nx = -1; ny = -1; }
+    if ((u >> (o - 1)) & 1u) { nx = -1; ny = 1; }
+    if ((u >> (o + 1)) & 1u) { nx = 1; ny = 1; }
+    if ((d >> o) & 1u) { nx = 0; ny = -1; }
+    if ((u >> o) & 1u) { nx = 0; ny = 1; }
+    if ((c >> (o - 1)) & 1u) { nx = -1; ny = 0; }
+    if ((c >> (o + 1)) & 1u) { nx = 1; ny = 0; }
+    if (nx != SDL_NONE) {
+        s.n0x = s.ax = nx;
+        s.n0y = s.ay = ny;
+        sdl_start_query(s, SDL_MODE_APEX);
+    } else {
+        sdl_start_query(s, SDL_MODE_NEAREST);
+    }
+}
+
+// exact in float32: all operands are integers below 2^24 (coordinates relative to s, |.| <= 31 between window points)
+SD_FN bool sdl_inside(int ax, int ay, int px, int py, int cx, int cy) {
+    // is c inside circle(s = origin, a, p), with (s, a, p) counter-clockwise ?  (perturbed, never a tie)
+    const float adx = (float)(0 - cx), ady = (float)(0 - cy), bdx = (float)(ax - cx), bdy = (float)(ay - cy);
+    const float cdx = (float)(px - cx), cdy = (float)(py - cy);
+    const float ad = adx * adx + ady * ady, bd = bdx * bdx + bdy * bdy, cd = cdx * cdx + cdy * cdy;
+    const float det = adx * (bdy * cd - bd * cdy) - ady * (bdx * cd - bd * cdx) + ad * (bdx * cdy - bdy * cdx);
+    if (det != 0.f) return det > 0.f;
+    // co-circular: the raster-first of s(0,0), a, p, c decides (see sd_inside)
+    const bool s_first = sd_before(0, 0, ax, ay) && sd_before(0, 0, px, py) && sd_before(0, 0, cx, cy);
+    const bool a_first = sd_before(ax, ay, 0, 0) && sd_before(ax, ay, px, py) && sd_before(ax, ay, cx, cy);
+    const bool p_first = sd_before(px, py, 0, 0) && sd_before(px, py, ax, ay) && sd_before(px, py, cx, cy);
+    if (s_first) return sd_orient(cx, cy, ax, ay, px, py) > 0;
+    if (a_first) return sd_orient(0, 0, cx, cy, px, py) > 0;
+    if (p_first) return sd_orient(0, 0, ax, ay, cx, cy) > 0;
+    return false;
+}
+
+SD_FN void sdl_set_apex(SdLocal& s, int cx, int cy) {
+    s.px = cx;
+    s.py = cy;
+    const float ax = (float)s.ax, ay = (float)s.ay, x = (float)cx, y = (float)cy;
+    const float d = 2.f * (ax * y - ay * x);  // > 0: c is strictly left of s -> a
+    const float a2 = ax * ax + ay * ay, c2 = x * x + y * y;
+    s.ux = (y * a2 - ay * c2) / d;
+    s.uy = (ax * c2 - x * a2) / d;
+    s.r2 = s.ux * s.ux + s.uy * s.uy;
+}
+
+// One iteration of the lane's state machine: (advance to the next window row if the current one is exhausted) and
+// (test one candidate if there is one).  `emit(ax, ay, bx, by, cx, cy)` receives owned triangles (absolute
+// coordinates, counter-clockwise).
+template <class Emit>
+SD_FN int sdl_iter(SdLocal& s, Emit& emit) {
+    if (s.bits == 0u) {
+        // ---- advance to the next window row (zig-zag away from row m), or finish the query.
+        //      Rows and columns are cut to the "mask circle": the candidate's circle once there is a candidate,
+        //      the small search disc around the edge before that (stage 0), nothing in stage 1.
+        const bool have = s.px != SDL_NONE;
+        const float mx = have ? s.ux : s.hx, my = have ? s.uy : s.hy;
+        const float mr2 = have ? s.r2 : (s.stage == 0 ? s.hr2 : 1e9f);
+        const float rad = sqrtf(mr2) + 0.75f;
+        int r = 0;
+        bool found = false;
+#pragma unroll
+        for (int attempt = 0; attempt < 2 && !found; attempt++) {
+            s.k++;
+            const int off = (s.k + 1) >> 1;
+            const bool up = (s.k & 1) != 0;
+            r = s.m + (up ? off : -off);
+            if (up) {
+                if (r > SDL_HALF || (float)r > my + rad) s.upDone = true;
+                found = !s.upDone;
+            } else {
+                if (r < -SDL_HALF || (float)r < my - rad) s.dnDone = true;
+                found = !s.dnDone;
+            }
+            if (s.upDone && s.dnDone) break;
+        }
+        if (found) {
+            const float dy = (float)r - my;
+            const float h2 = mr2 - dy * dy;
+            // float32 round-off of h2 is a few ulp of r^2: widen by it so that the mask stays a superset
+            const float half = sqrtf((h2 > 0.f ? h2 : 0.f) + 2e-6f * mr2) + 0.75f;
+            int xl = (int)floorf(fmaxf(mx - half, -64.f)), xr = (int)ceilf(fminf(mx + half, 64.f));
+            if (s.mode == SDL_MODE_APEX) {  // strictly left of s -> a:  ay * x < ax * y
+                const float t = (float)(s.ax * r);
+                if (s.ay > 0) {
+                    const int b = (int)ceilf(t / (float)s.ay);  // x <= ceil(t/ay) is a superset of x < t/ay
+                    if (b < xr) xr = b;
+                } else if (s.ay < 0) {
+                    const int b = (int)floorf(t / (float)s.ay);
+                    if (b > xl) xl = b;
+                } else if (t <= 0.f) {
+                    xr = xl - 1;
+                }
+            }
+            s.row = r;
+            s.bits = sdl_pick(s.W, r + SDL_HALF) & sdl_range_mask(xl, xr);
+        } else if (s.upDone && s.dnDone) {
+            // ---- sweep finished
+            if (s.mode == SDL_MODE_NEAREST) {
+                if (!have || s.r2 > (float)(SDL_HALF * SDL_HALF)) return SDL_SITE_HARD;  // a site outside the window could be nearer
+                s.n0x = s.ax = s.px;
+                s.n0y = s.ay = s.py;
+                sdl_start_query(s, SDL_MODE_APEX);
+                return SDL_CONTINUE;
+            }
+            if (s.stage == 0) {
+                // the stage-0 sweep saw every site of the search disc; is that all of the candidate's circle?
+                bool enough = false;
+                if (have) {
+                    const float dx = s.ux - s.hx, dy = s.uy - s.hy;
+                    const float gap = sqrtf(s.hr2) - sqrtf(s.r2) - 0.3f;
+                    enough = gap > 0.f && dx * dx + dy * dy < gap * gap;
+                }
+                if (!enough) {
+                    s.stage = 1;
+                    sdl_restart_scan(s);
+                    return SDL_CONTINUE;
+                }
+            }
+            if (!have) return SDL_SITE_HARD;  // nothing in the window (hull edge, or a far apex)
+            const float rr = sqrtf(s.r2) + 0.26f;
+            if (s.ux - rr < (float)SDL_XLO || s.ux + rr > (float)SDL_XHI || s.uy - rr < (float)-SDL_HALF ||
+                s.uy + rr > (float)SDL_HALF)
+                return SDL_SITE_HARD;  // the circle leaves the window: not certified
+            // triangle (s, a, p); s owns it iff it is the raster-first vertex
+            if (sd_before(0, 0, s.ax, s.ay) && sd_before(0, 0, s.px, s.py))
+                emit(s.sx, s.sy, s.sx + s.ax, s.sy + s.ay, s.sx + s.px, s.sy + s.py);
+            if (s.px == s.n0x && s.py == s.n0y) return SDL_SITE_DONE;
+            if (++s.deg > 64) return SDL_SITE_HARD;
+            s.ax = s.px;
+            s.ay = s.py;
+            sdl_start_query(s, SDL_MODE_APEX);
+            return SDL_CONTINUE;
+        }
+    }
+    if (s.bits != 0u) {
+        // ---- test one candidate
+        const int b = sd_ctz(s.bits);
+        s.bits &= s.bits - 1u;
+        const int x = b + SDL_XLO, y = s.row;
+        if (s.mode == SDL_MODE_NEAREST) {
+            const float d2 = (float)(x * x + y * y);
+            if (d2 < s.r2) {
+                s.px = x;
+                s.py = y;
+                s.r2 = d2;
+            }
+        } else if (s.ax * y - s.ay * x > 0) {  // strictly left of s -> a
+            if (s.px == SDL_NONE) {
+                sdl_set_apex(s, x, y);
+            } else {
+                const float ex = (float)x - s.ux, ey = (float)y - s.uy;
+                if (ex * ex + ey * ey <= s.r2 + 0.01f * (1.f + s.r2) && sdl_inside(s.ax, s.ay, s.px, s.py, x, y))
+                    sdl_set_apex(s, x, y);
+            }
+        }
+    }
+    return SDL_CONTINUE;
+}

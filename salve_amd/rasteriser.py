@@ -70,6 +70,7 @@ class RenderDebug:
     keys: Optional[torch.Tensor] = None  # int64 [n, H*W]
     mask: Optional[torch.Tensor] = None  # uint8 [n, H, W]
     stats: Optional[torch.Tensor] = None  # int32 [n, 8]
+    in_window: Optional[torch.Tensor] = None  # int32 [n]
 
 
 class BevRasteriser:
@@ -150,12 +151,13 @@ class BevRasteriser:
             dbg.keys = torch.empty((n, Hb * Wb), dtype=torch.int64, device=self.device)
             dbg.mask = torch.empty((n, Hb, Wb), dtype=torch.uint8, device=self.device)
             dbg.stats = torch.zeros((n, 8), dtype=torch.int32, device=self.device)
+            dbg.in_window = torch.zeros(n, dtype=torch.int32, device=self.device)
         ws = self._workspace(n)
         P = int(pano_rgb.shape[0])
         ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
         st = self.lib.salve_bev_render_batch(
             ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), P, ptr(self.sphere), ptr(hyps_dev), n,
-            ptr(out_bev), ptr(dbg.img_xy), ptr(dbg.keys), ptr(dbg.mask), ptr(dbg.stats), ptr(ws), ws.numel(), self._stream(),
+            ptr(out_bev), ptr(dbg.img_xy), ptr(dbg.keys), ptr(dbg.mask), ptr(dbg.stats), ptr(dbg.in_window), ptr(ws), ws.numel(), self._stream(),
         )
         _lib.check(st, "salve_bev_render_batch")
         return out_bev, dbg
@@ -176,6 +178,30 @@ class BevRasteriser:
                                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
         _lib.check(st, "salve_bev_densify")
         return out_bev
+
+    def render_counted(self, pano_rgb: torch.Tensor, pano_depth: torch.Tensor, hyps_dev: torch.Tensor, n: int,
+                       out_bev: torch.Tensor, counts: torch.Tensor) -> None:
+        """`render` that also reports, per render, how many points fell inside the window (int32 [n])."""
+        ws = self._workspace(n)
+        ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+        st = self.lib.salve_bev_render_batch(
+            ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), int(pano_rgb.shape[0]), ptr(self.sphere), ptr(hyps_dev), n,
+            ptr(out_bev), None, None, None, None, ptr(counts), ptr(ws), ws.numel(), self._stream())
+        _lib.check(st, "salve_bev_render_batch")
+
+    def render_points(self, xyz: np.ndarray, rgb_u8: np.ndarray):
+        """One BEV image from an explicit world-frame point cloud (host arrays).  Returns (int32 [1,H,W], n_in_window)."""
+        xyz_d = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float64)).to(self.device)
+        rgb_d = torch.from_numpy(np.ascontiguousarray(rgb_u8, dtype=np.uint8)).to(self.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ws = self._workspace(1)
+        st = self.lib.salve_bev_scatter_points(ctypes.byref(self.cfg), ctypes.c_void_p(xyz_d.data_ptr()), ctypes.c_void_p(rgb_d.data_ptr()),
+                                               int(xyz_d.shape[0]), ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                               ws.numel(), self._stream())
+        _lib.check(st, "salve_bev_scatter_points")
+        Hb, Wb = self.bev_hw
+        bev = self.densify(1, torch.empty((1, Hb, Wb), dtype=torch.int32, device=self.device))
+        return bev, int(cnt.item())
 
     def export_u8(self, bev: torch.Tensor) -> torch.Tensor:
         """int32 [n,H,W] -> uint8 [n,H,W,3] (the array `render_bev_image` returns)."""

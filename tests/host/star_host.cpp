@@ -37,3 +37,45 @@ extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H,
     memcpy(tri_xy, out.data(), out.size() * sizeof(int));
     return nt;
 }
+
+#include "../../salve_amd/csrc/star_local.h"
+
+// Local state machine for every site, general algorithm for the sites it hands over.  stats: [0] iterations,
+// [1] hard sites, [2] max iterations of one site.
+extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, int H, int W, int* tri_xy, int cap,
+                                           long long* stats) {
+    int wpr = (W + 31) / 32;
+    std::vector<uint32_t> occ((size_t)H * wpr, 0);
+    std::vector<int16_t> rmin(H, (int16_t)W), rmax(H, (int16_t)-1);
+    for (int i = 0; i < n; i++) {
+        occ[(size_t)ys[i] * wpr + (xs[i] >> 5)] |= 1u << (xs[i] & 31);
+        if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
+        if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
+    }
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data()};
+    std::vector<int> out;
+    Collect c = {&out};
+    long long iters = 0, hard = 0, maxit = 0;
+    for (int i = 0; i < n; i++) {
+        SdLocal st;
+        sdl_begin(st, g, xs[i], ys[i]);
+        std::vector<int> mine;
+        Collect cm = {&mine};
+        long long it = 0;
+        int r;
+        do { r = sdl_iter(st, cm); it++; } while (r == SDL_CONTINUE && it < 100000);
+        iters += it;
+        if (it > maxit) maxit = it;
+        if (r == SDL_SITE_DONE) {
+            out.insert(out.end(), mine.begin(), mine.end());
+        } else {
+            hard++;
+            if (sd_star(g, xs[i], ys[i], c) < 0) return -1;
+        }
+    }
+    if (stats) { stats[0] = iters; stats[1] = hard; stats[2] = maxit; }
+    int nt = (int)(out.size() / 6);
+    if (nt > cap) return -2;
+    memcpy(tri_xy, out.data(), out.size() * sizeof(int));
+    return nt;
+}

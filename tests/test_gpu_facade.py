@@ -1,0 +1,131 @@
+"""GPU tests of the reference-shaped API (salve_amd.utils.bev_rendering_utils, pipeline) and full-size properties."""
+
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import bev_oracle as bo  # noqa: E402
+from salve_amd import synthetic  # noqa: E402
+from salve_amd.common.bevparams import BEVParams  # noqa: E402
+from salve_amd.common.sim2 import Sim2  # noqa: E402
+from salve_amd.utils import bev_rendering_utils as bru  # noqa: E402
+from salve_amd.utils import image_io  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def panos():
+    return [synthetic.make_pano(i) for i in range(2)]
+
+
+def posed_cloud(pano, surface, R, t):
+    a = bo.xyzrgb_from_arrays(pano[1], pano[0], bo.floor_ceiling_z_range(surface))
+    a, _ = bo.pose_pair(a, a[:1], R, t)
+    return a
+
+
+def test_render_bev_image_from_point_cloud(panos):
+    hyp = synthetic.make_hypotheses(4, 2, seed=0)
+    for hi, surface in ((0, "floor"), (1, "ceiling")):
+        cloud = posed_cloud(panos[0], surface, hyp.R[hi], hyp.t[hi])
+        got = bru.render_bev_image(BEVParams(), cloud, is_semantics=False)
+        assert got.dtype == np.uint8 and got.shape == (501, 501, 3)
+        assert np.array_equal(got, bo.render_bev_image(cloud, mode="exact")["bev"])
+    far = cloud.copy()
+    far[:, :2] += 100.0
+    assert bru.render_bev_image(BEVParams(), far, False) is None  # no point in the window -> None (:279)
+    with pytest.raises(NotImplementedError):
+        bru.render_bev_image(BEVParams(), cloud, True)
+
+
+def test_render_bev_image_small_geometry():
+    rgb, depth = synthetic.make_pano(3, 64, 128)
+    hyp = synthetic.make_hypotheses(16, 1, seed=0)
+    grid = bo.BevGrid(100, 100, 0.1)
+    for hi in (0, 5, 9):
+        a = bo.xyzrgb_from_arrays(depth, rgb, bo.floor_ceiling_z_range("floor"))
+        a, _ = bo.pose_pair(a, a[:1], hyp.R[hi], hyp.t[hi])
+        exp = bo.render_bev_image(a, grid, mode="exact")
+        got = bru.render_bev_image(BEVParams(100, 100, 0.1), a, False)
+        if exp is None:
+            assert got is None
+        else:
+            assert np.array_equal(got, exp["bev"])
+
+
+def test_render_bev_pair_and_texture_map_files(panos, tmp_path):
+    from PIL import Image
+
+    raw = tmp_path / "raw" / "0001" / "panos"
+    raw.mkdir(parents=True)
+    depth_root = tmp_path / "depth"
+    paths = {}
+    for i, (rgb, d) in enumerate(panos):
+        p = raw / f"floor_01_partial_room_0{i}_pano_{i}.png"  # lossless stand-in for the panorama JPEG
+        Image.fromarray(rgb).save(p)
+        image_io.write_depth_png(str(depth_root / "0001" / f"{p.stem}.depth.png"), d)
+        paths[i] = str(p)
+    hyp = synthetic.make_hypotheses(2, 2, seed=0)
+    S = Sim2(hyp.R[0].astype(np.float64), hyp.t[0].astype(np.float64), 1.0)
+    args = SimpleNamespace(img_i1=paths[0], img_i2=paths[1], depth_i1=str(depth_root / "0001" / f"{raw.joinpath(paths[0]).stem}.depth.png"),
+                           depth_i2=str(depth_root / "0001" / f"{raw.joinpath(paths[1]).stem}.depth.png"), scale=0.001,
+                           crop_ratio=80 / 512, crop_z_range=[-float("inf"), -1.0])
+    img1, img2 = bru.render_bev_pair(args, "0001", "floor_01", 0, 1, S, False)
+    r1, r2 = bo.render_bev_pair(panos[0][0], panos[0][1], panos[1][0], panos[1][1], hyp.R[0], hyp.t[0], "floor", mode="exact")
+    assert np.array_equal(img1, r1["bev"]) and np.array_equal(img2, r2["bev"])
+    with pytest.raises(ValueError):
+        bru.render_bev_pair(SimpleNamespace(scale=0.001), "0001", "floor_01", 0, 1, S, False)
+    # the per-pair driver: names, files, idempotent restart
+    pair = tmp_path / "hyp" / "0_1__door_0_0_identity.json"
+    S.save_as_json(pair)
+    bev_root = tmp_path / "bev"
+    call = (paths, "floor", str(pair), 7, "gt_alignment_approx", str(bev_root), "0001", "floor_01", str(depth_root), ["rgb_texture"], None, None)
+    bru.generate_texture_maps_for_pair(*call)
+    out = sorted(p.name for p in (bev_root / "gt_alignment_approx" / "0001").iterdir())
+    assert out == ["pair_7___door_0_0_identity_floor_rgb_floor_01_partial_room_00_pano_0.jpg",
+                   "pair_7___door_0_0_identity_floor_rgb_floor_01_partial_room_01_pano_1.jpg"]
+    first = (bev_root / "gt_alignment_approx" / "0001" / out[0])
+    mtime = first.stat().st_mtime_ns
+    bru.generate_texture_maps_for_pair(*call)
+    assert first.stat().st_mtime_ns == mtime
+    back = np.asarray(Image.open(first))
+    assert back.shape == (501, 501, 3) and np.abs(back.astype(int) - img1.astype(int)).mean() < 6  # JPEG is lossy
+
+
+def test_full_size_properties():
+    """Size-independent properties on the benchmark-size workload (no oracle needed)."""
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from salve_amd.pipeline import RenderVerifyPipeline
+
+    dev = torch.device("cuda:0")
+    P, N = 8, 96
+    panos = [synthetic.make_pano(i) for i in range(P)]
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    pipe = RenderVerifyPipeline(model, dev, chunk=64)
+    pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
+    table = synthetic.make_hypotheses(N, P, seed=1)
+    # identity pose through the posed branch == the cached identity render
+    table.R[0] = np.eye(2, dtype=np.float32)
+    table.t[0] = 0
+    prep = pipe.prepare(table)
+    a = pipe.score(prep).clone()
+    first_chunk_bev = pipe.bev[:32].clone()
+    b = pipe.score(prep)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)  # deterministic
+    assert torch.isfinite(a).all()
+    pipe2 = RenderVerifyPipeline(model, dev, chunk=32)
+    pipe2.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
+    c = pipe2.score(pipe2.prepare(table))
+    torch.cuda.synchronize()
+    assert torch.equal(a, c)  # independent of the batching
+    pipe.score(pipe.prepare(table.shard(0, 3)))  # first 32 hypotheses land in bev[0:32]
+    torch.cuda.synchronize()
+    assert torch.equal(pipe.bev[0], pipe.ref_bev[int(table.i1[0])])
+    # two ranks' shards reproduce the single-rank logits
+    parts = [pipe.score(pipe.prepare(table.shard(r, 2))).clone() for r in range(2)]
+    assert torch.equal(torch.cat(parts), a)

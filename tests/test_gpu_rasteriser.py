@@ -120,7 +120,7 @@ def test_bad_arguments_are_reported(setup):
     ras, panos, d_rgb, d_depth, hyp = setup
     import ctypes
 
-    st = ras.lib.salve_bev_render_batch(ctypes.byref(ras.cfg), None, None, 1, None, None, 1, None, None, None, None, None, None, 0, None)
+    st = ras.lib.salve_bev_render_batch(ctypes.byref(ras.cfg), None, None, 1, None, None, 1, None, None, None, None, None, None, None, 0, None)
     assert st == -1 and b"null" in ras.lib.salve_last_error()
     with pytest.raises(_lib.SalveHipError):
         ras.tiles(torch.zeros(1, device=ras.device, dtype=torch.int32), ras.upload_tile_jobs([0], [0], [0]), 1,

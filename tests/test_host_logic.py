@@ -1,0 +1,216 @@
+"""Host-side logic of salve_amd (no GPU): tables, packing, program builder, sharding, API mirrors."""
+
+import json
+import re
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bev_oracle as bo
+from oracle import resnet_oracle as ro
+from salve_amd import _lib, synthetic
+from salve_amd.common.bevparams import BEVParams, get_line_width_by_resolution
+from salve_amd.common.sim2 import Sim2
+from salve_amd.models import hip_resnet
+from salve_amd.models.early_fusion import EarlyFusionCEResnet
+from salve_amd.rasteriser import linear_resize_taps, normalisation_lut, pack_hypotheses
+from salve_amd.utils import image_io
+from salve_amd.utils.hohonet_pano_utils import get_sphere_factors, get_uni_sphere_xyz
+from salve_amd.utils.rotation_utils import rotmat2d
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "salve_hip.h").read_text()
+    declared = set(re.findall(r"\b(salve_[a-z0-9_]+)\s*\(", header))
+    declared -= {"salve_status_t"}
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.salve_hip_version() == 1
+    assert lib.salve_last_error() is not None
+
+
+def test_product_has_no_cpu_path():
+    from salve_amd.rasteriser import BevRasteriser
+
+    with pytest.raises(_lib.SalveHipError):
+        BevRasteriser(torch.device("cpu"))
+    with pytest.raises(_lib.SalveHipError):
+        hip_resnet.HipResNet({}, 50, torch.device("cpu"))
+    if not torch.cuda.is_available():
+        from salve_amd.utils import bev_rendering_utils
+
+        with pytest.raises(_lib.SalveHipError):
+            bev_rendering_utils.render_bev_image(BEVParams(), np.zeros((4, 6)), False)
+
+
+def test_product_never_imports_the_oracle():
+    for p in (ROOT / "salve_amd").rglob("*.py"):
+        if p.name == "smoke.py":  # smoke() is allowed to check against the oracle
+            continue
+        assert "oracle" not in re.sub(r"#.*", "", p.read_text()).replace("the oracle", ""), p
+
+
+def test_sphere_table_matches_oracle():
+    for hw in ((512, 1024), (64, 128)):
+        assert np.array_equal(get_uni_sphere_xyz(*hw), bo.sphere_table(*hw))
+        r, z, c, s = get_sphere_factors(*hw)
+        t = bo.sphere_table(*hw)
+        assert np.array_equal(r[:, None] * c[None, :], t[..., 0]) and np.array_equal(z, t[:, 0, 2])
+
+
+def test_resize_taps_and_lut_match_oracle():
+    for dst, src in ((234, 501), (224, 501), (512, 1000), (300, 299)):
+        s0, s1, a0, a1 = bo._linear_coeffs(dst, src)
+        t = linear_resize_taps(dst, src)
+        assert np.array_equal(t, np.stack([s0, s1, a0, a1], -1))
+    lut = normalisation_lut()
+    img = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, 2)
+    t = bo.tile_from_bev(img, resize_hw=(16, 16), crop_hw=(16, 16))
+    for c in range(3):
+        assert np.array_equal(t[c].reshape(-1), lut[c])
+
+
+def test_host_resize_matches_oracle_and_box_average():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(40, 60, 3), dtype=np.uint8)
+    assert np.array_equal(image_io.resize_linear_u8(img, (17, 23)), bo.resize_linear_u8(img, (17, 23)))
+    half = image_io.resize_linear_u8(img, (20, 30))
+    a = img.astype(int)
+    assert np.array_equal(half, (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2)
+    assert image_io.resize_linear_u8(img, (40, 60)) is img
+
+
+def test_hypothesis_packing_and_sharding():
+    hyp = synthetic.make_hypotheses(100, 7, seed=3)
+    assert hyp.R.dtype == np.float32 and hyp.t.dtype == np.float32 and (hyp.i1 != hyp.i2).all()
+    h = pack_hypotheses(hyp.i1, np.zeros(100), hyp.R, hyp.t, np.ones(100))
+    raw = h.view(np.uint8).reshape(100, 40)
+    assert np.array_equal(raw[:, 0:4].copy().view(np.int32)[:, 0], hyp.i1)
+    assert np.array_equal(raw[:, 8:24].copy().view(np.float32), hyp.R.reshape(100, 4))
+    assert np.array_equal(raw[:, 24:32].copy().view(np.float32), hyp.t)
+    parts = [hyp.shard(r, 8) for r in range(8)]
+    assert sum(len(p) for p in parts) == 100
+    assert np.array_equal(np.concatenate([p.i1 for p in parts]), hyp.i1)
+    assert np.array_equal(synthetic.make_hypotheses(100, 7, seed=3).t, hyp.t)  # deterministic
+
+
+def test_sim2_mirror():
+    g = np.load(ROOT / "tests" / "golden" / "g5_sim2.npz")
+    S = Sim2(R=rotmat2d(33.3), t=np.array([0.25, -1.75]), s=1.0)
+    assert S.rotation.dtype == np.float32 and np.array_equal(S.rotation, g["R32"]) and np.array_equal(S.translation, g["t32"])
+    assert np.array_equal(S.transform_from(g["pts"]), g["S_pts"])
+    assert np.array_equal(BEVParams().bevimg_Sim2_world.transform_from(g["pts"]), g["img_pts"])
+    # algebra (reference tests/common/test_sim2.py)
+    a = Sim2(rotmat2d(90), np.array([1.0, 2.0]), 3.0)
+    I = a.compose(a.inverse())
+    assert np.allclose(I.rotation, np.eye(2), atol=1e-6) and np.allclose(I.translation, 0, atol=1e-6) and np.isclose(I.scale, 1)
+    assert a == Sim2.from_matrix(a.matrix)
+    pts = np.array([[1.0, 0.0], [0.0, 2.0]])
+    assert np.allclose(a.inverse().transform_from(a.transform_from(pts)), pts, atol=1e-5)
+    with pytest.raises(ValueError):
+        Sim2(np.eye(3), np.zeros(2), 1.0)
+    with pytest.raises(ZeroDivisionError):
+        Sim2(np.eye(2), np.zeros(2), 0.0)
+    with pytest.raises(ValueError):
+        a.transform_from(np.zeros((3, 3)))
+
+
+def test_sim2_json_roundtrip(tmp_path):
+    a = Sim2(rotmat2d(-12.5), np.array([0.5, -2.0]), 1.0)
+    f = tmp_path / "d" / "0_1__door_0_0_identity.json"
+    a.save_as_json(f)
+    d = json.loads(f.read_text())
+    assert set(d) == {"R", "t", "s"} and len(d["R"]) == 4 and len(d["t"]) == 2
+    b = Sim2.from_json(f)
+    assert np.array_equal(a.rotation, b.rotation) and np.array_equal(a.translation, b.translation) and b.scale == 1.0
+
+
+def test_bevparams_mirror():
+    p = BEVParams(img_h=20, img_w=20, meters_per_px=0.5)
+    assert p.xlims == [-5, 5] and p.ylims == [-5, 5]
+    got = p.bevimg_Sim2_world.transform_from(np.array([[2, 2], [-5, -5], [5, 5]]))
+    assert np.allclose(got, [[14, 14], [0, 0], [20, 20]])
+    assert [get_line_width_by_resolution(r) for r in (0.005, 0.01, 0.02)] == [30, 15, 8]
+
+
+def test_model_state_dict_layout_and_program():
+    torch.manual_seed(0)
+    for layers, modalities, cin in ((50, ["floor_rgb_texture"], 6), (18, ["layout"], 6),
+                                    (152, ["ceiling_rgb_texture", "floor_rgb_texture"], 12)):
+        m = EarlyFusionCEResnet(layers, False, 2, SimpleNamespace(modalities=modalities))
+        assert list(m.conv1.weight.shape) == [64, cin, 7, 7]
+        assert set(m.state_dict()) == set(ro.expected_state_dict_keys(layers, cin // 3))
+    m = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"]))
+    sd = {"module." + k: v for k, v in m.state_dict().items()}  # DataParallel checkpoints
+    ops, w, p, k, cin_p = hip_resnet.build_program(sd, 50)
+    assert cin_p == 8 and len(ops) == 1 + 1 + 16 * 3 + 4 + 1
+    convs = ops[ops["op"] == 0]
+    assert (convs["Cout"] % 64 == 0).all() and ((convs["KH"] * convs["KW"] * convs["Cin"]) % 64 == 0).all()
+    assert convs["w_off"][-1] + convs["Cout"][-1] * convs["KH"][-1] * convs["KW"][-1] * convs["Cin"][-1] == w.size
+    flops = 2 * (convs["Ho"].astype(np.int64) * convs["Wo"] * convs["Cout"] * convs["KH"] * convs["KW"] * convs["Cin"]).sum()
+    assert 8.3e9 < flops < 9.6e9  # 8.41 GFLOP algorithmic + the stem's zero padding
+    assert tuple(ops[-1][["Hi", "Wi", "Cin", "Cout"]]) == (7, 7, 2048, 2)
+
+
+def test_bn_folding_is_exact_algebra():
+    torch.manual_seed(1)
+    w = torch.randn(8, 4, 3, 3)
+    bn = {"weight": torch.rand(8) + 0.5, "bias": torch.randn(8), "running_mean": torch.randn(8), "running_var": torch.rand(8) + 0.5}
+    x = torch.randn(2, 4, 9, 9)
+    wf, bf = hip_resnet.fold_bn(w, bn)
+    ref = torch.nn.functional.batch_norm(torch.nn.functional.conv2d(x, w, None, 1, 1), bn["running_mean"], bn["running_var"],
+                                         bn["weight"], bn["bias"], False, 0.0, 1e-5)
+    assert torch.allclose(torch.nn.functional.conv2d(x, wf, bf, 1, 1), ref, atol=1e-5)
+
+
+def test_unsupported_modalities_raise_like_the_reference():
+    with pytest.raises(RuntimeError):
+        EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture", "layout"]))
+
+
+def test_training_config_loader(tmp_path):
+    from salve_amd.training_config import load_training_config
+
+    y = tmp_path / "c.yaml"
+    y.write_text("TrainingConfig:\n    _target_: salve.training_config.TrainingConfig\n    lr_annealing_strategy: poly\n    base_lr: 0.001\n"
+                 "    weight_decay: 0.0001\n    num_ce_classes: 2\n    print_every: 10\n    poly_lr_power: 0.9\n    optimizer_algo: adam\n"
+                 "    num_layers: 152\n    pretrained: True\n    dataparallel: True\n    resize_h: 234\n    resize_w: 234\n    train_h: 224\n"
+                 "    train_w: 224\n    apply_photometric_augmentation: False\n    modalities: [\"ceiling_rgb_texture\", \"floor_rgb_texture\"]\n"
+                 "    cfg_stem:\n    num_epochs: 50\n    workers: 15\n    batch_size: 256\n    data_root: /x\n    layout_data_root:\n"
+                 "    model_save_dirpath: /y\n    gpu_ids:\n")
+    c = load_training_config(str(y))
+    assert c.num_layers == 152 and c.resize_h == 234 and c.train_h == 224 and c.modalities == ("ceiling_rgb_texture", "floor_rgb_texture")
+
+
+def test_checkpoint_loader_accepts_dataparallel_prefix(tmp_path):
+    from salve_amd import train_utils
+
+    args = SimpleNamespace(modalities=["floor_rgb_texture"], num_layers=18, pretrained=False, num_ce_classes=2, dataparallel=True)
+    torch.manual_seed(0)
+    src = EarlyFusionCEResnet(18, False, 2, args)
+    ck = tmp_path / "train_ckpt.pth"
+    torch.save({"epoch": 3, "state_dict": {"module." + k: v for k, v in src.state_dict().items()}}, ck)
+    dst = EarlyFusionCEResnet(18, False, 2, args)
+    train_utils.load_model_checkpoint(str(ck), dst, args)
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+    with pytest.raises(RuntimeError):
+        train_utils.load_model_checkpoint(str(tmp_path / "missing.pth"), dst, args)
+
+
+def test_install_as_salve_alias():
+    import salve_amd
+
+    salve_amd.install_as_salve()
+    import salve.common.sim2 as s2
+    import salve.utils.bev_rendering_utils as b
+
+    assert s2.Sim2 is Sim2 and callable(b.generate_texture_maps_for_pair)
+    assert b.bev_fname_from_img_fpath(58, "opening_0_0_rotated", "floor", "/x/floor_01_partial_room_01_pano_13.jpg") == \
+        "pair_58___opening_0_0_rotated_floor_rgb_floor_01_partial_room_01_pano_13.jpg"

@@ -1,0 +1,85 @@
+"""The GPU's Delaunay star algorithms (salve_amd/csrc/star_delaunay.h, star_local.h), compiled for the HOST with g++
+from the very same headers, against the independent CPU oracle (incremental insertion + flips)."""
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import bev_oracle as bo
+from salve_amd import synthetic
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    so = tmp_path_factory.mktemp("star") / "star_host.so"
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", str(so), str(ROOT / "tests" / "host" / "star_host.cpp")], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def run(fn, pts, H, W):
+    xs = np.ascontiguousarray(pts[:, 0], dtype=np.int32)
+    ys = np.ascontiguousarray(pts[:, 1], dtype=np.int32)
+    cap = 2 * len(xs) + 16
+    out = np.zeros((cap, 6), dtype=np.int32)
+    stats = np.zeros(4, dtype=np.int64)
+    nt = fn(xs.ctypes.data_as(ctypes.c_void_p), ys.ctypes.data_as(ctypes.c_void_p), len(xs), H, W, out.ctypes.data_as(ctypes.c_void_p), cap,
+            stats.ctypes.data_as(ctypes.c_void_p))
+    assert nt >= 0
+    v = out[:nt].reshape(-1, 3, 2)
+    return sorted(map(tuple, np.sort(v[:, :, 1] * 4096 + v[:, :, 0], 1).tolist())), stats
+
+
+def oracle_tris(pts):
+    order, tri = bo.delaunay_exact(pts[:, 0], pts[:, 1])
+    sp = pts[order]
+    return sorted(map(tuple, np.sort(sp[tri][:, :, 1] * 4096 + sp[tri][:, :, 0], 1).tolist()))
+
+
+@pytest.mark.parametrize("which", ["star_host_triangulate", "star_host_triangulate_local"])
+def test_random_lattice_sets(lib, which):
+    rng = np.random.default_rng(5)
+    done = 0
+    for _ in range(250):
+        G = int(rng.integers(3, 60))
+        pts = np.unique(rng.integers(0, G, size=(int(rng.integers(3, 500)), 2)), axis=0)
+        if bo._is_degenerate(pts):
+            continue
+        ref = oracle_tris(pts)
+        if not ref:
+            continue
+        got, _ = run(getattr(lib, which), pts, G, G)
+        assert got == ref
+        done += 1
+    assert done > 150
+
+
+def test_structured_degenerate_sets(lib):
+    """Full lattices, lines with one off-point, rings: maximal co-circularity and collinear hulls."""
+    yy, xx = np.mgrid[0:12, 0:17]
+    full = np.stack([xx.ravel(), yy.ravel()], 1)
+    line = np.array([[i, 3] for i in range(20)] + [[7, 9]])
+    th = np.linspace(0, 2 * np.pi, 80, endpoint=False)
+    ring = np.unique(np.round(np.stack([30 + 25 * np.cos(th), 30 + 25 * np.sin(th)], 1)).astype(int), axis=0)
+    for pts, G in ((full, 17), (line, 20), (ring, 61), (full[::2], 17)):
+        ref = oracle_tris(pts)
+        for which in ("star_host_triangulate", "star_host_triangulate_local"):
+            assert run(getattr(lib, which), pts, G, G)[0] == ref
+
+
+def test_realistic_render_sites(lib):
+    hyp = synthetic.make_hypotheses(16, 2, seed=0)
+    p0, p1 = synthetic.make_pano(0), synthetic.make_pano(1)
+    a = bo.xyzrgb_from_arrays(p0[1], p0[0], bo.floor_ceiling_z_range("floor"))
+    a, _ = bo.pose_pair(a, a[:1], hyp.R[0], hyp.t[0])
+    res = bo.render_bev_image(a, mode="exact")
+    sp, tri = res["site_xy_sorted"], res["tri"]
+    ref = sorted(map(tuple, np.sort(sp[tri][:, :, 1] * 4096 + sp[tri][:, :, 0], 1).tolist()))
+    got, stats = run(lib.star_host_triangulate_local, sp, 501, 501)
+    assert got == ref
+    assert stats[1] < 0.05 * len(sp)  # only a few per cent of the sites need the general walk
+    assert run(lib.star_host_triangulate, sp, 501, 501)[0] == ref
