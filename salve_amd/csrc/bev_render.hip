@@ -146,7 +146,8 @@ struct RasterEmit {
     const uint32_t* msk;
     const unsigned long long* keys;
     uint32_t* bev;  // output image of this render
-    int flip;       // H - 1 to flip vertically (np.flipud), else 0 with sign handled below
+    int flip;       // H - 1 to flip vertically (np.flipud), -1: no flip
+    int lane, nlanes;  // rows lane, lane + nlanes, ... of the bounding box (several lanes may share one triangle)
     bool skip;
 
     __device__ __forceinline__ uint32_t blend(int32_t wa, int32_t wb, int32_t wc, int32_t area, uint32_t ca,
@@ -171,7 +172,7 @@ struct RasterEmit {
         uint32_t ca = 0, cb = 0, cc = 0;
         bool have = false;
         const bool wide = (x1 - x0) > 40;
-        for (int y = y0; y <= y1; y++) {
+        for (int y = y0 + lane; y <= y1; y += nlanes) {
             int xa = x0, xb = x1;
             if (wide) {
                 // exact span of the triangle on this row: intersect the three half-planes E_i(x) = A_i x + D_i >= 0
@@ -390,8 +391,8 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     //      E2: hard sites (hull, sparse regions: a few %) walk their star with the general algorithm and rasterise
     //          in place.   F: all lanes rasterise the queued triangles.
     if (!degenerate && !(c.dbg_flags & 1)) {
-        SdGrid g = {H, W, wpr, occ, rmin, rmax};
-        RasterEmit raster = {H, W, wpr, occ, msk, keys, bev, (c.out_flags & 1) ? -1 : H - 1, (c.dbg_flags & 2) != 0};
+        SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1};
+        RasterEmit raster = {H, W, wpr, occ, msk, keys, bev, (c.out_flags & 1) ? -1 : H - 1, 0, 1, (c.dbg_flags & 2) != 0};
         QueueEmit qemit = {triq, &scal[8], H * W, raster};
         SdLocal st;
         bool active = false;
@@ -417,9 +418,17 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
         const int nhard = scal[7];
         const int nq = min(scal[8], H * W);
         int err = 0;
-        for (int i = tid; i < ((c.dbg_flags & 4) ? 0 : nhard); i += DENSIFY_THREADS) {
-            const uint32_t s = __hip_atomic_load(hardlist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (sd_star(g, (int)(s & 0xFFFFu), (int)(s >> 16), raster) < 0) err = 1;
+        {   // E2: one wavefront per hard site; its row sweeps and its rasterisation are shared by the 64 lanes
+            SdGrid gw = g;
+            gw.lane = lane;
+            gw.nlanes = 64;
+            RasterEmit rw = raster;
+            rw.lane = lane;
+            rw.nlanes = 64;
+            for (int i = wave; i < ((c.dbg_flags & 4) ? 0 : nhard); i += nwaves) {
+                const uint32_t s = __hip_atomic_load(hardlist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sd_star(gw, (int)(s & 0xFFFFu), (int)(s >> 16), rw) < 0) err = 1;
+            }
         }
         if (err) atomicOr(&scal[5], 1);
         for (int i = tid; i < ((c.dbg_flags & 8) ? 0 : nq); i += DENSIFY_THREADS) {

@@ -31,6 +31,9 @@ struct SdGrid {
     const uint32_t* occ;  // [H][wpr] occupancy bits, bit (x & 31) of word x >> 5
     const int16_t* rmin;  // [H] smallest occupied x of the row, or W if the row is empty
     const int16_t* rmax;  // [H] largest occupied x of the row, or -1
+    // Row sweeps can be shared by the lanes of a wavefront that all work on the SAME site: this caller then visits
+    // rows lane, lane + nlanes, ... of every sweep and the lanes merge their candidates (sd_share_best).
+    int lane, nlanes;     // 0, 1 for a caller that sweeps alone
 };
 
 SD_FN int32_t sd_orient(int ax, int ay, int bx, int by, int cx, int cy) {
@@ -146,7 +149,7 @@ SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir
     // dir * orient(s, a, (x, y)) = P (y - sy) - Q (x - sx) >= 1
     const double P = (double)(dir * (ax - sx)), Q = (double)(dir * (ay - sy));
     const double invQ = Q != 0.0 ? 1.0 / Q : 0.0;
-    for (int y = ya; step > 0 ? y <= yb : y >= yb; y += step) {
+    for (int y = ya + g.lane * step; step > 0 ? y <= yb : y >= yb; y += g.nlanes * step) {
         SD_COUNT(rows);
         int x0 = xa > g.rmin[y] ? xa : g.rmin[y];
         int x1 = xb < g.rmax[y] ? xb : g.rmax[y];
@@ -207,6 +210,26 @@ SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir
     }
 }
 
+// Merge the candidates of the lanes that share a sweep: a butterfly of exact comparisons, after which every lane holds
+// the same best apex.  (The order "c beats p" is total under the perturbation, so both partners of an exchange agree.)
+SD_FN void sd_share_best(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int* px, int* py, SdCircle* circ) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (g.nlanes > 1) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            const int ox = __shfl_xor(*px, off), oy = __shfl_xor(*py, off);
+            const bool differs = ox >= 0 && (ox != *px || oy != *py);
+            if (differs && (*px < 0 || sd_better(sx, sy, ax, ay, *px, *py, ox, oy, dir))) {
+                *px = ox;
+                *py = oy;
+            }
+        }
+        if (*px >= 0) *circ = sd_circle(sx, sy, ax, ay, *px, *py);
+    }
+#else
+    (void)g; (void)sx; (void)sy; (void)ax; (void)ay; (void)dir; (void)px; (void)py; (void)circ;
+#endif
+}
+
 #ifndef SD_WINDOW_MARGIN
 #define SD_WINDOW_MARGIN 2
 #endif
@@ -226,6 +249,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     if (wy1 > g.H - 1) wy1 = g.H - 1;
     if (wx1 > g.W - 1) wx1 = g.W - 1;
     sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, wx0, wx1, &px, &py, &circ);
+    sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
     if (px >= 0) {
         // 2. whatever part of the candidate's circle sticks out of the window (and is on the image) is swept too
         const double r = sqrt(circ.r2) + 1.0;
@@ -235,10 +259,12 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         if (cy1 > wy1 || cy0 < wy0 || cx0 < wx0 || cx1 > wx1) {
             SD_COUNT(apex_slow);
             if (cy1 > wy1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy1 + 1, cy1, 1, cx0, cx1, &px, &py, &circ);
+            sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
             if (cy0 < wy0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0 - 1, cy0, -1, cx0, cx1, &px, &py, &circ);
             const int ry0 = cy0 > wy0 ? cy0 : wy0, ry1 = cy1 < wy1 ? cy1 : wy1;
             if (cx0 < wx0) sd_scan_rows(g, sx, sy, ax, ay, dir, ry0, ry1, 1, cx0, wx0 - 1, &px, &py, &circ);
             if (cx1 > wx1) sd_scan_rows(g, sx, sy, ax, ay, dir, ry0, ry1, 1, wx1 + 1, cx1, &px, &py, &circ);
+            sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
         }
     } else {
         // 3. nothing near the edge: the window's rows outside its columns, then away from the window downwards
@@ -246,8 +272,11 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         SD_COUNT(apex_far);
         if (wx0 > 0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, 0, wx0 - 1, &px, &py, &circ);
         if (wx1 < g.W - 1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, wx1 + 1, g.W - 1, &px, &py, &circ);
+        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
         if (wy1 < g.H - 1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy1 + 1, g.H - 1, 1, 0, g.W - 1, &px, &py, &circ);
+        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
         if (wy0 > 0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0 - 1, 0, -1, 0, g.W - 1, &px, &py, &circ);
+        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
     }
     *outx = px;
     *outy = py;

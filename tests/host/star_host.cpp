@@ -22,7 +22,7 @@ extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H,
         if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
         if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
     }
-    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data()};
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1};
     std::vector<int> out;
     Collect c = {&out};
     long long steps = 0;
@@ -52,7 +52,7 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
         if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
         if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
     }
-    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data()};
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1};
     std::vector<int> out;
     Collect c = {&out};
     long long iters = 0, hard = 0, maxit = 0;
