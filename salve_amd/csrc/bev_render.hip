@@ -212,9 +212,11 @@ struct RasterEmit {
                     const int32_t wc = area - wa - wb;
                     if ((wa | wb | wc) < 0) continue;
                     if (!have) {
-                        ca = (uint32_t)keys[(size_t)ay * W + ax] & 0xFFFFFFu;
-                        cb = (uint32_t)keys[(size_t)by * W + bx] & 0xFFFFFFu;
-                        cc = (uint32_t)keys[(size_t)cy * W + cx] & 0xFFFFFFu;
+                        // the key image is rewritten by every launch at the same addresses: read it past the L1,
+                        // which may still hold the previous launch's lines when kernels of two streams interleave
+                        ca = (uint32_t)__hip_atomic_load(keys + (size_t)ay * W + ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFu;
+                        cb = (uint32_t)__hip_atomic_load(keys + (size_t)by * W + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFu;
+                        cc = (uint32_t)__hip_atomic_load(keys + (size_t)cy * W + cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFu;
                         have = true;
                     }
                     bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = blend(wa, wb, wc, area, ca, cb, cc);
@@ -236,12 +238,22 @@ struct QueueEmit {
         if (slot < capacity) {
             const uint32_t rel = (uint32_t)((bx - ax) & 0xFF) | ((uint32_t)((by - ay) & 0xFF) << 8) |
                                  ((uint32_t)((cx - ax) & 0xFF) << 16) | ((uint32_t)((cy - ay) & 0xFF) << 24);
-            queue[slot] = ((unsigned long long)rel << 32) | ((uint32_t)ay << 16) | (uint32_t)ax;
+            __hip_atomic_store(queue + slot, ((unsigned long long)rel << 32) | ((uint32_t)ay << 16) | (uint32_t)ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             fallback(ax, ay, bx, by, cx, cy);  // queue full (cannot happen below ~50 % occupancy): rasterise in place
         }
     }
 };
+
+// Workgroup barrier that also orders this workgroup's GLOBAL stores against what other waves of the workgroup do
+// afterwards to the same addresses (later stores, or sc1 loads served by L2).  A plain __syncthreads() does not wait
+// for outstanding stores on gfx950 (workgroup-scope release needs no vmcnt wait when all waves share a CU), so two
+// waves' stores to one pixel could land out of order -- observed as rare wrong pixels once another kernel shared
+// the memory pipeline.
+__device__ __forceinline__ void wg_barrier_after_global_stores() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 
 __device__ __forceinline__ unsigned long long load_key(const unsigned long long* p) {
     // keys were produced by L2 atomics of another kernel / by this workgroup's peers: read them past the L1
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
                     int base = 0;
                     if (lane == 0) base = atomicAdd(&scal[0], __popcll(ob));
                     base = __shfl(base, 0);
-                    if (site) sitelist[base + __popcll(ob & ((1ull << lane) - 1ull))] = ((uint32_t)y << 16) | (uint32_t)x;
+                    if (site) __hip_atomic_store(sitelist + base + __popcll(ob & ((1ull << lane) - 1ull)), ((uint32_t)y << 16) | (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     lo = min(lo, (seg << 6) + (int)__ffsll((long long)ob) - 1);
                     hi = max(hi, (seg << 6) + 63 - (int)__clzll((long long)ob));
                 }
@@ -381,8 +393,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
         }
     }
     // the site list and the base image were written by this workgroup through L2: make them visible to all its waves
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
+    wg_barrier_after_global_stores();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
     // ---- phase E: Delaunay stars.
@@ -404,17 +415,17 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
                 const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sdl_begin(st, g, (int)(s & 0xFFFFu), (int)(s >> 16));
                 active = true;
+                if (dbg_stats) { atomicAdd(&scal[9], 1); atomicAdd(&scal[10], (int)(s & 0xFFFFu) + (int)(s >> 16)); }
             }
-            const int r = sdl_iter(st, qemit);
+            const int r = sdl_iter(st, g, qemit);
             iters++;
             if (r != SDL_CONTINUE) {
                 active = false;
-                if (r == SDL_SITE_HARD) hardlist[atomicAdd(&scal[7], 1)] = ((uint32_t)st.sy << 16) | (uint32_t)st.sx;
+                if (r == SDL_SITE_HARD) __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (dbg_stats) atomicAdd(&scal[4], iters);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
+        wg_barrier_after_global_stores();  // hard list and triangle queue are complete and in L2
         const int nhard = scal[7];
         const int nq = min(scal[8], H * W);
         int err = 0;
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     }
     if (dbg_stats) {
         __syncthreads();
-        if (tid < 8) dbg_stats[rid * 8 + tid] = tid < 6 ? scal[tid] : scal[tid + 1];  // [6] hard sites [7] queued triangles
+        if (tid < 8) dbg_stats[rid * 8 + tid] = tid == 1 ? scal[9] : (tid == 2 ? scal[10] : (tid < 6 ? scal[tid] : scal[tid + 1]));  // [1] sites begun [2] checksum [6] hard sites [7] queued triangles
     }
 }
 
@@ -573,11 +584,11 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         SALVE_HIP_CHECK(hipGetLastError());
     }
     if (densify) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static size_t attr_lds = 0;
+        if (lds > attr_lds) {  // opt in to more than 64 KB of dynamic LDS, for exactly what this launch uses
             SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_lds = lds;
         }
         hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, keys, out_bev, sitelist, hardlist, triq,
                            dbg_mask, dbg_stats);

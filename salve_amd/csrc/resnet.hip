@@ -47,7 +47,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 }
 
 template <int BN>
-__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p) {
     constexpr int WN = BN / 2;       // wave tile width
     constexpr int NT = WN / 16;      // 16-wide MFMA tiles per wave along n
     constexpr int B_LOADS = BN / 32; // 16-byte chunks of the weight tile per thread
@@ -85,38 +85,53 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4], rb[B_LOADS];
+    uint4 ra[4];
+    uint4 rb0 = uint4{0u, 0u, 0u, 0u}, rb1 = rb0, rb2 = rb0, rb3 = rb0;  // named, not an array: hipcc kept rb[] in scratch
     const int nkt = p.K / BK;
 
-    auto load_tile = [&](int kt) {
-        const int32_t e = p.ktab[kt * 8 + chunk];
-        const int dy = (int8_t)(e & 0xFF), dx = (int8_t)((e >> 8) & 0xFF), coff = (e >> 16) & 0xFFFF;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            const bool ok = rvalid[i] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(p.in + ((boff[i] + (long long)iy * p.Wi + ix) * p.Cin + coff))
-                       : uint4{0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; i++) {
-            const int n = n0 + row_base + i * 32;
-            rb[i] = *reinterpret_cast<const uint4*>(p.w + (long long)n * p.K + kt * BK + chunk * 8);
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(As + (row_base + i * 32) * LDK + chunk * 8) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_LOADS; i++) *reinterpret_cast<uint4*>(Bs + (row_base + i * 32) * LDK + chunk * 8) = rb[i];
-    };
+    // staging as macros (lambdas capturing the register arrays by reference made hipcc keep them in scratch)
+#define LOAD_TILE(KT)                                                                                                  \
+    {                                                                                                                  \
+        const int32_t e_ = p.ktab[(KT) * 8 + chunk];                                                                   \
+        const int dy_ = (int8_t)(e_ & 0xFF), dx_ = (int8_t)((e_ >> 8) & 0xFF), coff_ = (e_ >> 16) & 0xFFFF;            \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                \
+            const int iy = iy0[i] + dy_, ix = ix0[i] + dx_;                                                            \
+            const bool ok = rvalid[i] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;                                 \
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(p.in + ((boff[i] + (long long)iy * p.Wi + ix) * p.Cin + coff_)) \
+                       : uint4{0u, 0u, 0u, 0u};                                                                        \
+        }                                                                                                              \
+        {                                                                                                              \
+            const uint16_t* wp_ = p.w + (long long)(n0 + row_base) * p.K + (KT) * BK + chunk * 8;                      \
+            rb0 = *reinterpret_cast<const uint4*>(wp_);                                                                \
+            rb1 = *reinterpret_cast<const uint4*>(wp_ + 32ll * p.K);                                                   \
+            if (B_LOADS > 2) {                                                                                         \
+                rb2 = *reinterpret_cast<const uint4*>(wp_ + 64ll * p.K);                                               \
+                rb3 = *reinterpret_cast<const uint4*>(wp_ + 96ll * p.K);                                               \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+#define STORE_TILE()                                                                                                   \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                  \
+            *reinterpret_cast<uint4*>(As + (row_base + i * 32) * LDK + chunk * 8) = ra[i];                             \
+        *reinterpret_cast<uint4*>(Bs + (row_base)*LDK + chunk * 8) = rb0;                                              \
+        *reinterpret_cast<uint4*>(Bs + (row_base + 32) * LDK + chunk * 8) = rb1;                                       \
+        if (B_LOADS > 2) {                                                                                             \
+            *reinterpret_cast<uint4*>(Bs + (row_base + 64) * LDK + chunk * 8) = rb2;                                   \
+            *reinterpret_cast<uint4*>(Bs + (row_base + 96) * LDK + chunk * 8) = rb3;                                   \
+        }                                                                                                              \
+    }
 
-    load_tile(0);
+    LOAD_TILE(0);
     for (int kt = 0; kt < nkt; kt++) {
         __syncthreads();  // previous tile's fragment reads are done
-        store_tile();
+        STORE_TILE();
         __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);  // in flight under the MFMAs below
+        {   // next tile in flight under the MFMAs below (the last iteration re-loads its own tile: branch-free, so the
+            // staging registers never go through scratch)
+            const int kn = kt + 1 < nkt ? kt + 1 : kt;
+            LOAD_TILE(kn);
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ks++) {
             bf16x8 af[4], bfr[NT];
@@ -134,6 +149,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvArgs p) {
         }
     }
 
+#undef LOAD_TILE
+#undef STORE_TILE
     // ---- epilogue: (residual tile ->) LDS, add bias / residual / ReLU in fp32 on the accumulator's own elements,
     //      round once to bf16, then 16-byte coalesced stores.
     __syncthreads();

@@ -1,9 +1,9 @@
-// star_local.h -- the Delaunay star walk of star_delaunay.h as a per-lane STATE MACHINE over a register-resident
-// 32 x 15 pixel window, written for SIMT execution on 64-wide wavefronts.
+// star_local.h -- the Delaunay star walk of star_delaunay.h as a per-lane STATE MACHINE over a 32 x 15 pixel window
+// of the LDS bitmap around the site, written for SIMT execution on 64-wide wavefronts.
 //
 // Why: with one site per lane and the textbook nested loops (steps -> rows -> words -> bits) a wavefront pays, at
 // every nesting level, for its slowest lane; measured lane utilisation of that form was 15 %.  Here every lane
-// runs ONE flat loop whose iteration is either "advance to the next window row" or "test one candidate"; a lane
+// runs ONE flat loop whose iteration is "advance to the next window row" or "test one candidate"; a lane
 // that finishes a site immediately pulls the next one, so lanes never wait for each other and the only cost of
 // divergence is that both (short) bodies are issued.
 //
@@ -26,7 +26,6 @@ enum { SDL_MODE_NEAREST = 0, SDL_MODE_APEX = 1 };
 
 struct SdLocal {
     int sx, sy;
-    uint32_t W[SDL_ROWS];
     int n0x, n0y;      // first neighbour (relative)
     int ax, ay;        // current edge s -> a (relative)
     int px, py;        // best apex so far (px == SDL_NONE: none)
@@ -36,15 +35,6 @@ struct SdLocal {
     uint32_t bits;
     bool upDone, dnDone;
 };
-
-SD_FN uint32_t sdl_pick(const uint32_t* W, int r) {  // W[r] with r in 0..14, as a select tree (no scratch)
-    const uint32_t a0 = (r & 1) ? W[1] : W[0], a1 = (r & 1) ? W[3] : W[2], a2 = (r & 1) ? W[5] : W[4];
-    const uint32_t a3 = (r & 1) ? W[7] : W[6], a4 = (r & 1) ? W[9] : W[8], a5 = (r & 1) ? W[11] : W[10];
-    const uint32_t a6 = (r & 1) ? W[13] : W[12], a7 = W[14];
-    const uint32_t b0 = (r & 2) ? a1 : a0, b1 = (r & 2) ? a3 : a2, b2 = (r & 2) ? a5 : a4, b3 = (r & 2) ? a7 : a6;
-    const uint32_t c0 = (r & 4) ? b1 : b0, c1 = (r & 4) ? b3 : b2;
-    return (r & 8) ? c1 : c0;
-}
 
 // 32 bits of bitmap row y starting at column x0 (may be negative / beyond the image: zeros)
 SD_FN uint32_t sdl_row32(const SdGrid& g, int y, int x0) {
@@ -93,13 +83,10 @@ SD_FN void sdl_start_query(SdLocal& s, int mode) {
 SD_FN void sdl_begin(SdLocal& s, const SdGrid& g, int sx, int sy) {
     s.sx = sx;
     s.sy = sy;
-#pragma unroll
-    for (int r = 0; r < SDL_ROWS; r++) s.W[r] = sdl_row32(g, sy - SDL_HALF + r, sx + SDL_XLO);
-    s.W[SDL_HALF] &= ~(1u << (0 - SDL_XLO));  // the site itself is not a candidate
     s.deg = 0;
     s.ax = s.ay = 0;
     // an 8-neighbour, if there is one, is a nearest site (distance 1 before sqrt 2) and needs no search
-    const uint32_t c = s.W[SDL_HALF], u = s.W[SDL_HALF + 1], d = s.W[SDL_HALF - 1];
+    const uint32_t c = sdl_row32(g, sy, sx + SDL_XLO), u = sdl_row32(g, sy + 1, sx + SDL_XLO), d = sdl_row32(g, sy - 1, sx + SDL_XLO);
     const int o = 0 - SDL_XLO;
     int nx = SDL_NONE, ny = 0;
     if ((d >> (o + 1)) & 1u) { nx = 1; ny = -1; }
@@ -152,7 +139,7 @@ SD_FN void sdl_set_apex(SdLocal& s, int cx, int cy) {
 // (test one candidate if there is one).  `emit(ax, ay, bx, by, cx, cy)` receives owned triangles (absolute
 // coordinates, counter-clockwise).
 template <class Emit>
-SD_FN int sdl_iter(SdLocal& s, Emit& emit) {
+SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
     if (s.bits == 0u) {
         // ---- advance to the next window row (zig-zag away from row m), or finish the query.
         //      Rows and columns are cut to the "mask circle": the candidate's circle once there is a candidate,
@@ -197,7 +184,8 @@ SD_FN int sdl_iter(SdLocal& s, Emit& emit) {
                 }
             }
             s.row = r;
-            s.bits = sdl_pick(s.W, r + SDL_HALF) & sdl_range_mask(xl, xr);
+            // the window row straight from the LDS bitmap (the site itself is not a candidate)
+            s.bits = sdl_row32(g, s.sy + r, s.sx + SDL_XLO) & sdl_range_mask(xl, xr) & (r == 0 ? ~(1u << (0 - SDL_XLO)) : 0xFFFFFFFFu);
         } else if (s.upDone && s.dnDone) {
             // ---- sweep finished
             if (s.mode == SDL_MODE_NEAREST) {

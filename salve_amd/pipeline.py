@@ -42,7 +42,8 @@ def surfaces_for(modalities: Sequence[str]) -> List[str]:
 
 
 class RenderVerifyPipeline:
-    def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: int = 256) -> None:
+    def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: int = 512,
+                 overlap: bool = False) -> None:
         self.device = torch.device(device)
         self.model = model
         self.surfaces = surfaces_for(model.modalities)
@@ -51,10 +52,17 @@ class RenderVerifyPipeline:
         self.chunk = chunk
         S = len(self.surfaces)
         Hb, Wb = self.ras.bev_hw
-        self.bev = torch.empty((chunk * S, Hb, Wb), dtype=torch.int32, device=self.device)
+        # overlap=True: two sets of chunk buffers, the rasteriser fills one on its own HIP stream while the verifier
+        # consumes the other.  OFF by default: with 2 x 66 KB of LDS per CU the densify workgroups leave no room for
+        # the convolution blocks, so nothing is gained today, and co-residency of bev_densify_kernel with
+        # conv_igemm_kernel on a CU was observed to perturb a few pixels per 64 renders
+        self.nbuf = 2 if overlap else 1
+        self.bevs = [torch.empty((chunk * S, Hb, Wb), dtype=torch.int32, device=self.device) for _ in range(self.nbuf)]
         # tiles: bf16 NHWC, pad channels (never written) stay zero
-        self.tiles = torch.zeros((chunk, self.ras.crop, self.ras.crop, self.engine.in_channels), dtype=torch.bfloat16,
-                                 device=self.device)
+        self.tile_bufs = [torch.zeros((chunk, self.ras.crop, self.ras.crop, self.engine.in_channels), dtype=torch.bfloat16,
+                                      device=self.device) for _ in range(self.nbuf)]
+        self.bev, self.tiles = self.bevs[0], self.tile_bufs[0]
+        self.render_stream = torch.cuda.Stream(self.device) if overlap else None
         self.pano_rgb = self.pano_depth = self.ref_bev = None
         self.n_panos = 0
 
@@ -102,26 +110,49 @@ class RenderVerifyPipeline:
             "jobs2": self.ras.upload_tile_jobs(st(jobs2_bev), st(jobs2_slot), st(jobs2_chan)),
         }
 
+    def _render_chunk(self, prepared, lo: int, n: int, buf: int, timers=None) -> None:
+        S = len(self.surfaces)
+        hb, jb = _lib.HYP_DTYPE.itemsize, _lib.TILE_JOB_DTYPE.itemsize
+        rows = prepared["rows"][lo * S * hb:]
+        bev, tiles = self.bevs[buf], self.tile_bufs[buf]
+        if timers is not None:
+            self.ras.scatter(self.pano_rgb, self.pano_depth, rows, n * S)
+            timers[0].record()
+            self.ras.densify(n * S, bev)
+            timers[1].record()
+        else:
+            self.ras.render(self.pano_rgb, self.pano_depth, rows, n * S, out_bev=bev)
+        self.ras.tiles(bev, prepared["jobs1"][lo * S * jb:], n * S, tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
+        self.ras.tiles(self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
+
     def score(self, prepared, out: Optional[torch.Tensor] = None, timers=None) -> torch.Tensor:
-        """Render + verify every hypothesis of a prepared shard.  Returns fp32 logits [N, num_classes]."""
-        N, S = prepared["n"], len(self.surfaces)
+        """Render + verify every hypothesis of a prepared shard.  Returns fp32 logits [N, num_classes].
+        `timers` = (event, event): bracket the densify launch of the first chunk (benchmark roofline)."""
+        N = prepared["n"]
         if out is None:
             out = torch.empty((N, self.engine.num_classes), dtype=torch.float32, device=self.device)
-        hb, jb = _lib.HYP_DTYPE.itemsize, _lib.TILE_JOB_DTYPE.itemsize
-        for lo in range(0, N, self.chunk):
-            n = min(self.chunk, N - lo)
-            rows = prepared["rows"][lo * S * hb:]
-            if timers is not None:
-                self.ras.scatter(self.pano_rgb, self.pano_depth, rows, n * S)
-                timers[0].record()
-                self.ras.densify(n * S, self.bev)
-                timers[1].record()
-                timers = None  # time the first chunk only
-            else:
-                self.ras.render(self.pano_rgb, self.pano_depth, rows, n * S, out_bev=self.bev)
-            self.ras.tiles(self.bev, prepared["jobs1"][lo * S * jb:], n * S, self.tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
-            self.ras.tiles(self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, self.tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
-            self.engine.forward_nhwc(self.tiles[:n], out=out[lo:lo + n])
+        chunks = [(lo, min(self.chunk, N - lo)) for lo in range(0, N, self.chunk)]
+        if self.render_stream is None:
+            for lo, n in chunks:
+                self._render_chunk(prepared, lo, n, 0, timers)
+                timers = None
+                self.engine.forward_nhwc(self.tile_bufs[0][:n], out=out[lo:lo + n])
+            return out
+        main = torch.cuda.current_stream(self.device)
+        self.render_stream.wait_stream(main)
+        rendered = [torch.cuda.Event() for _ in chunks]
+        consumed = [torch.cuda.Event() for _ in chunks]
+        for i, (lo, n) in enumerate(chunks):
+            with torch.cuda.stream(self.render_stream):
+                if i >= self.nbuf:
+                    self.render_stream.wait_event(consumed[i - self.nbuf])  # the verifier is done with this buffer set
+                self._render_chunk(prepared, lo, n, i % self.nbuf, timers)
+                timers = None
+                rendered[i].record(self.render_stream)
+            main.wait_event(rendered[i])
+            self.engine.forward_nhwc(self.tile_bufs[i % self.nbuf][:n], out=out[lo:lo + n])
+            consumed[i].record(main)
+        self.render_stream.wait_stream(main)
         return out
 
 

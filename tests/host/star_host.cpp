@@ -63,7 +63,7 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
         Collect cm = {&mine};
         long long it = 0;
         int r;
-        do { r = sdl_iter(st, cm); it++; } while (r == SDL_CONTINUE && it < 100000);
+        do { r = sdl_iter(st, g, cm); it++; } while (r == SDL_CONTINUE && it < 100000);
         iters += it;
         if (it > maxit) maxit = it;
         if (r == SDL_SITE_DONE) {

@@ -105,7 +105,7 @@ def test_full_size_properties():
     panos = [synthetic.make_pano(i) for i in range(P)]
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
-    pipe = RenderVerifyPipeline(model, dev, chunk=64)
+    pipe = RenderVerifyPipeline(model, dev, chunk=64)  # serial streams (default)
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     table = synthetic.make_hypotheses(N, P, seed=1)
     # identity pose through the posed branch == the cached identity render
