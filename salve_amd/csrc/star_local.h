@@ -59,7 +59,14 @@ SD_FN void sdl_restart_scan(SdLocal& s) {
     s.upDone = s.dnDone = false;
 }
 
-SD_FN void sdl_start_query(SdLocal& s, int mode) {
+SD_FN bool sdl_bit(const SdGrid& g, int x, int y) {
+    return x >= 0 && x < g.W && y >= 0 && y < g.H && ((g.occ[y * g.wpr + (x >> 5)] >> (x & 31)) & 1u);
+}
+
+SD_FN void sdl_set_apex(SdLocal& s, int cx, int cy);
+SD_FN bool sdl_inside(int ax, int ay, int px, int py, int cx, int cy);
+
+SD_FN void sdl_start_query(SdLocal& s, const SdGrid& g, int mode) {
     s.mode = mode;
     s.px = SDL_NONE;
     s.py = 0;
@@ -71,6 +78,33 @@ SD_FN void sdl_start_query(SdLocal& s, int mode) {
         s.hy = 0.5f * (float)s.ay;
         const float hr = 0.5f * sqrtf((float)(s.ax * s.ax + s.ay * s.ay)) + 2.5f;
         s.hr2 = hr * hr;
+        // Unit edges (most edges where the image is densely covered): the apex is a corner of the unit square on the
+        // left of s -> a whenever that corner is a site -- the square's circumcircle has no lattice point strictly
+        // inside, and a tie between its two left corners is settled by the perturbation.  No sweep needed then.
+        if (s.ax >= -1 && s.ax <= 1 && s.ay >= -1 && s.ay <= 1) {
+            const int nx = -s.ay, ny = s.ax;  // left normal
+            int cx = SDL_NONE, cy = 0;
+            if (s.ax == 0 || s.ay == 0) {
+                const bool b1 = sdl_bit(g, s.sx + nx, s.sy + ny), b2 = sdl_bit(g, s.sx + s.ax + nx, s.sy + s.ay + ny);
+                if (b1 && b2) {
+                    const bool second = sdl_inside(s.ax, s.ay, nx, ny, s.ax + nx, s.ay + ny);
+                    cx = second ? s.ax + nx : nx;
+                    cy = second ? s.ay + ny : ny;
+                } else if (b1) {
+                    cx = nx; cy = ny;
+                } else if (b2) {
+                    cx = s.ax + nx; cy = s.ay + ny;
+                }
+            } else {
+                const int qx = (s.ax + nx) / 2, qy = (s.ay + ny) / 2;  // exact: both sums are even
+                if (sdl_bit(g, s.sx + qx, s.sy + qy)) { cx = qx; cy = qy; }
+            }
+            if (cx != SDL_NONE) {
+                sdl_set_apex(s, cx, cy);
+                s.stage = 1;
+                s.upDone = s.dnDone = true;  // the next iteration goes straight to the end-of-query logic
+            }
+        }
     } else {
         s.m = 0;
         s.hx = s.hy = 0.f;
@@ -100,9 +134,9 @@ SD_FN void sdl_begin(SdLocal& s, const SdGrid& g, int sx, int sy) {
     if (nx != SDL_NONE) {
         s.n0x = s.ax = nx;
         s.n0y = s.ay = ny;
-        sdl_start_query(s, SDL_MODE_APEX);
+        sdl_start_query(s, g, SDL_MODE_APEX);
     } else {
-        sdl_start_query(s, SDL_MODE_NEAREST);
+        sdl_start_query(s, g, SDL_MODE_NEAREST);
     }
 }
 
@@ -151,7 +185,7 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
         int r = 0;
         bool found = false;
 #pragma unroll
-        for (int attempt = 0; attempt < 2 && !found; attempt++) {
+        for (int attempt = 0; attempt < 2 && !found && !(s.upDone && s.dnDone); attempt++) {
             s.k++;
             const int off = (s.k + 1) >> 1;
             const bool up = (s.k & 1) != 0;
@@ -192,7 +226,7 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
                 if (!have || s.r2 > (float)(SDL_HALF * SDL_HALF)) return SDL_SITE_HARD;  // a site outside the window could be nearer
                 s.n0x = s.ax = s.px;
                 s.n0y = s.ay = s.py;
-                sdl_start_query(s, SDL_MODE_APEX);
+                sdl_start_query(s, g, SDL_MODE_APEX);
                 return SDL_CONTINUE;
             }
             if (s.stage == 0) {
@@ -221,7 +255,7 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
             if (++s.deg > 64) return SDL_SITE_HARD;
             s.ax = s.px;
             s.ay = s.py;
-            sdl_start_query(s, SDL_MODE_APEX);
+            sdl_start_query(s, g, SDL_MODE_APEX);
             return SDL_CONTINUE;
         }
     }
