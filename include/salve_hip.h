@@ -119,6 +119,22 @@ int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_be
 int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, const uint8_t* rgb, int32_t n_points,
                              int32_t* n_in_window, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Stand-alone forms of the three utilities the reference exposes next to the renderer.
+ * salve_zorder_winners: zorder_utils.choose_elevated_repeated_vals (salve/utils/zorder_utils.py:10-83) -- x, y device
+ *   int32 [n] pixel coordinates, z device double [n], planes device double [n_slices+1] (np.linspace(zmin, zmax, ..)),
+ *   scratch device uint64 [img_h*img_w], valid device uint8 [n] (1 = the point wins its pixel).
+ * salve_remove_hallucinated: interpolation_utils.remove_hallucinated_content (salve/utils/interpolation_utils.py:74-122) --
+ *   sparse / interp / out device uint8 [H,W,3], scratch device uint8 [H*W].
+ * salve_bev_keys_from_pixels: the input side of interpolation_utils.interp_dense_grid_from_sparse (:21-54) -- xy device
+ *   int32 [n,2] (x, y) pixels, rgb device uint8 [n,3]; fills key image 0; follow with salve_bev_densify(cfg, 1, ...) using
+ *   cfg.out_flags = 3 (no flip, no mask) to obtain the interpolated image. */
+int salve_zorder_winners(const int32_t* x, const int32_t* y, const double* z, int32_t n, const double* planes, int32_t n_slices,
+                         int32_t img_w, int32_t img_h, uint64_t* scratch, uint8_t* valid, void* stream);
+int salve_remove_hallucinated(const uint8_t* sparse, const uint8_t* interp, int32_t H, int32_t W, int32_t K, uint8_t* scratch,
+                              uint8_t* out, void* stream);
+int salve_bev_keys_from_pixels(const salve_bev_config_t* cfg, const int32_t* xy, const uint8_t* rgb, int32_t n_points, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* BEV uint32 -> uint8 [n, bev_h, bev_w, 3], the array render_bev_image returns (bev_rendering_utils.py:328). */
 int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream);
 

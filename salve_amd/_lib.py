@@ -26,6 +26,9 @@ EXPORTED_SYMBOLS = (
     "salve_bev_scatter",
     "salve_bev_densify",
     "salve_bev_scatter_points",
+    "salve_zorder_winners",
+    "salve_remove_hallucinated",
+    "salve_bev_keys_from_pixels",
     "salve_bev_export_u8",
     "salve_bev_tiles",
     "salve_resnet_create",
@@ -90,6 +93,12 @@ def load() -> ctypes.CDLL:
     lib.salve_bev_densify.restype = ctypes.c_int
     lib.salve_bev_scatter_points.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, sz, vp]
     lib.salve_bev_scatter_points.restype = ctypes.c_int
+    lib.salve_zorder_winners.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, vp]
+    lib.salve_zorder_winners.restype = ctypes.c_int
+    lib.salve_remove_hallucinated.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.salve_remove_hallucinated.restype = ctypes.c_int
+    lib.salve_bev_keys_from_pixels.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, sz, vp]
+    lib.salve_bev_keys_from_pixels.restype = ctypes.c_int
     lib.salve_bev_export_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.salve_bev_export_u8.restype = ctypes.c_int
     lib.salve_bev_tiles.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]

@@ -511,6 +511,70 @@ __global__ __launch_bounds__(256) void bev_export_kernel(const uint32_t* __restr
     out[3 * i + 2] = (uint8_t)(v >> 16);
 }
 
+// ------------------------------------------------------------------------------------------------ stand-alone utilities
+// zorder_utils.choose_elevated_repeated_vals (zorder_utils.py:10-83) for arbitrary slice planes.
+__global__ __launch_bounds__(256) void zorder_splat_kernel(const int32_t* __restrict__ x, const int32_t* __restrict__ y,
+                                                           const double* __restrict__ z, int n, const double* __restrict__ planes,
+                                                           int nslices, int w, int h, unsigned long long* __restrict__ img) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double zi = z[i];
+    int slice = -1;
+    for (int k = 0; k < nslices; k++)
+        if (zi >= planes[k] && zi < planes[k + 1]) slice = k;
+    if (slice < 0 || x[i] < 0 || x[i] >= w || y[i] < 0 || y[i] >= h) return;
+    atomicMax(img + (size_t)y[i] * w + x[i], ((unsigned long long)(slice + 1) << 32) | (unsigned)i);
+}
+
+__global__ __launch_bounds__(256) void zorder_mark_kernel(const int32_t* __restrict__ x, const int32_t* __restrict__ y, int n, int w,
+                                                          int h, const unsigned long long* __restrict__ img, uint8_t* __restrict__ valid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool v = false;
+    if (x[i] >= 0 && x[i] < w && y[i] >= 0 && y[i] < h) {
+        const unsigned long long k = img[(size_t)y[i] * w + x[i]];
+        v = k != 0 && (unsigned)(k & 0xFFFFFFFFull) == (unsigned)i;
+    }
+    valid[i] = v ? 1 : 0;
+}
+
+// interpolation_utils.remove_hallucinated_content (:74-122) on arbitrary H x W x 3 uint8 images and kernel size K.
+__global__ __launch_bounds__(256) void halluc_rows_kernel(const uint8_t* __restrict__ sparse, int H, int W, int K,
+                                                          uint8_t* __restrict__ rowany) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)H * W) return;
+    const int y = (int)(i / W), x = (int)(i % W), p = K / 2;
+    bool any = false;
+    for (int xx = x - p; xx < x - p + K && !any; xx++) {
+        if (xx < 0 || xx >= W) continue;
+        const uint8_t* c = sparse + ((size_t)y * W + xx) * 3;
+        any = (((unsigned)c[0] * c[1] * c[2]) & 255u) != 0;  // the uint8 product wraps, as in the reference (:95)
+    }
+    rowany[i] = any ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void halluc_apply_kernel(const uint8_t* __restrict__ rowany, const uint8_t* __restrict__ interp,
+                                                           int H, int W, int K, uint8_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)H * W) return;
+    const int y = (int)(i / W), x = (int)(i % W), p = K / 2;
+    bool any = false;
+    for (int yy = y - p; yy < y - p + K && !any; yy++)
+        if (yy >= 0 && yy < H) any = rowany[(size_t)yy * W + x] != 0;
+    for (int ch = 0; ch < 3; ch++) out[3 * i + ch] = any ? interp[3 * i + ch] : 0;
+}
+
+// interp_dense_grid_from_sparse (:21-54): sites given as pixel coordinates + colours -> key image (last index wins).
+__global__ __launch_bounds__(256) void keys_from_pixels_kernel(const int32_t* __restrict__ xy, const uint8_t* __restrict__ rgb, int n,
+                                                               int W, int H, unsigned long long* __restrict__ kimg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    if (x < 0 || x >= W || y < 0 || y >= H) return;
+    const uint32_t col = (uint32_t)rgb[3 * (size_t)i] | ((uint32_t)rgb[3 * (size_t)i + 1] << 8) | ((uint32_t)rgb[3 * (size_t)i + 2] << 16);
+    atomicMax(kimg + (size_t)y * W + x, (1ull << 45) | ((unsigned long long)i << 24) | col);
+}
+
 bool make_devcfg(const salve_bev_config_t* cfg, DevCfg* d) {
     if (!cfg) return salve_fail("null config");
     if (cfg->pano_w <= 0 || cfg->pano_w % 4 != 0) return salve_fail("pano_w must be a positive multiple of 4");
@@ -636,6 +700,54 @@ int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, c
     if (n_points > 0) {
         hipLaunchKernelGGL(bev_scatter_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, d, xyz, rgb, n_points, keys,
                            n_in_window);
+        SALVE_HIP_CHECK(hipGetLastError());
+    }
+    return SALVE_OK;
+}
+
+int salve_zorder_winners(const int32_t* x, const int32_t* y, const double* z, int32_t n, const double* planes, int32_t n_slices,
+                         int32_t img_w, int32_t img_h, uint64_t* scratch, uint8_t* valid, void* stream) {
+    if (n == 0) return SALVE_OK;
+    if (n < 0 || !x || !y || !z || !planes || !scratch || !valid || n_slices < 1 || img_w <= 0 || img_h <= 0) {
+        salve_fail("salve_zorder_winners: bad argument");
+        return SALVE_ERR_BAD_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SALVE_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)img_w * img_h * sizeof(uint64_t), s));
+    hipLaunchKernelGGL(zorder_splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, planes, n_slices, img_w, img_h,
+                       reinterpret_cast<unsigned long long*>(scratch));
+    hipLaunchKernelGGL(zorder_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n, img_w, img_h,
+                       reinterpret_cast<const unsigned long long*>(scratch), valid);
+    SALVE_HIP_CHECK(hipGetLastError());
+    return SALVE_OK;
+}
+
+int salve_remove_hallucinated(const uint8_t* sparse, const uint8_t* interp, int32_t H, int32_t W, int32_t K, uint8_t* scratch,
+                              uint8_t* out, void* stream) {
+    if (!sparse || !interp || !scratch || !out || H <= 0 || W <= 0 || K < 1) {
+        salve_fail("salve_remove_hallucinated: bad argument");
+        return SALVE_ERR_BAD_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)(((long long)H * W + 255) / 256);
+    hipLaunchKernelGGL(halluc_rows_kernel, dim3(blocks), dim3(256), 0, s, sparse, H, W, K, scratch);
+    hipLaunchKernelGGL(halluc_apply_kernel, dim3(blocks), dim3(256), 0, s, scratch, interp, H, W, K, out);
+    SALVE_HIP_CHECK(hipGetLastError());
+    return SALVE_OK;
+}
+
+int salve_bev_keys_from_pixels(const salve_bev_config_t* cfg, const int32_t* xy, const uint8_t* rgb, int32_t n_points, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    DevCfg d;
+    if (!make_devcfg(cfg, &d)) return SALVE_ERR_BAD_ARG;
+    if (n_points < 0 || !workspace || (n_points > 0 && (!xy || !rgb))) { salve_fail("salve_bev_keys_from_pixels: bad argument"); return SALVE_ERR_BAD_ARG; }
+    if ((long long)n_points >= (1ll << 21)) { salve_fail("at most 2^21 - 1 points"); return SALVE_ERR_UNSUPPORTED; }
+    if (workspace_bytes < salve_bev_workspace_bytes(cfg, 1)) { salve_fail("workspace too small"); return SALVE_ERR_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    SALVE_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)d.H * d.W * sizeof(unsigned long long), s));
+    if (n_points > 0) {
+        hipLaunchKernelGGL(keys_from_pixels_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, xy, rgb, n_points, d.W, d.H, keys);
         SALVE_HIP_CHECK(hipGetLastError());
     }
     return SALVE_OK;

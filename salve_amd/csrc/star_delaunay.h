@@ -212,9 +212,13 @@ SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir
 
 // Merge the candidates of the lanes that share a sweep: a butterfly of exact comparisons, after which every lane holds
 // the same best apex.  (The order "c beats p" is total under the perturbation, so both partners of an exchange agree.)
-SD_FN void sd_share_best(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int* px, int* py, SdCircle* circ) {
+SD_FN void sd_share_best(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int* px, int* py, SdCircle* circ,
+                         int* shared_x, int* shared_y) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (g.nlanes > 1) {
+        // nothing to merge if no lane improved on the candidate all lanes agreed on last time (the common case for
+        // sweeps outside the window)
+        if (!__any(*px != *shared_x || *py != *shared_y)) return;
         for (int off = 32; off >= 1; off >>= 1) {
             const int ox = __shfl_xor(*px, off), oy = __shfl_xor(*py, off);
             const bool differs = ox >= 0 && (ox != *px || oy != *py);
@@ -224,9 +228,11 @@ SD_FN void sd_share_best(const SdGrid& g, int sx, int sy, int ax, int ay, int di
             }
         }
         if (*px >= 0) *circ = sd_circle(sx, sy, ax, ay, *px, *py);
+        *shared_x = *px;
+        *shared_y = *py;
     }
 #else
-    (void)g; (void)sx; (void)sy; (void)ax; (void)ay; (void)dir; (void)px; (void)py; (void)circ;
+    (void)g; (void)sx; (void)sy; (void)ax; (void)ay; (void)dir; (void)px; (void)py; (void)circ; (void)shared_x; (void)shared_y;
 #endif
 }
 
@@ -237,7 +243,7 @@ SD_FN void sd_share_best(const SdGrid& g, int sx, int sy, int ax, int ay, int di
 // Apex of the Delaunay triangle on side dir of the Delaunay edge s->a.  Returns false iff there is no site
 // strictly on that side, i.e. s->a is a hull edge.
 SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int* outx, int* outy) {
-    int px = -1, py = -1;
+    int px = -1, py = -1, shx = -1, shy = -1;  // shx, shy: the candidate all sharing lanes last agreed on
     SdCircle circ = {0, 0, 0};
     SD_COUNT(apex);
     // 1. a small window around the edge finds the apex in dense regions
@@ -249,7 +255,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     if (wy1 > g.H - 1) wy1 = g.H - 1;
     if (wx1 > g.W - 1) wx1 = g.W - 1;
     sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, wx0, wx1, &px, &py, &circ);
-    sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
+    sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
     if (px >= 0) {
         // 2. whatever part of the candidate's circle sticks out of the window (and is on the image) is swept too
         const double r = sqrt(circ.r2) + 1.0;
@@ -259,12 +265,12 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         if (cy1 > wy1 || cy0 < wy0 || cx0 < wx0 || cx1 > wx1) {
             SD_COUNT(apex_slow);
             if (cy1 > wy1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy1 + 1, cy1, 1, cx0, cx1, &px, &py, &circ);
-            sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
+            sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
             if (cy0 < wy0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0 - 1, cy0, -1, cx0, cx1, &px, &py, &circ);
             const int ry0 = cy0 > wy0 ? cy0 : wy0, ry1 = cy1 < wy1 ? cy1 : wy1;
             if (cx0 < wx0) sd_scan_rows(g, sx, sy, ax, ay, dir, ry0, ry1, 1, cx0, wx0 - 1, &px, &py, &circ);
             if (cx1 > wx1) sd_scan_rows(g, sx, sy, ax, ay, dir, ry0, ry1, 1, wx1 + 1, cx1, &px, &py, &circ);
-            sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
+            sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
         }
     } else {
         // 3. nothing near the edge: the window's rows outside its columns, then away from the window downwards
@@ -272,11 +278,11 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         SD_COUNT(apex_far);
         if (wx0 > 0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, 0, wx0 - 1, &px, &py, &circ);
         if (wx1 < g.W - 1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, wx1 + 1, g.W - 1, &px, &py, &circ);
-        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
+        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
         if (wy1 < g.H - 1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy1 + 1, g.H - 1, 1, 0, g.W - 1, &px, &py, &circ);
-        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
+        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
         if (wy0 > 0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0 - 1, 0, -1, 0, g.W - 1, &px, &py, &circ);
-        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ);
+        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
     }
     *outx = px;
     *outy = py;

@@ -1,0 +1,100 @@
+"""GPU tests of the stand-alone utilities (z-order, interpolation, mask) and of the 2048x1024 / ResNet-152 4-tuple config."""
+
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import bev_oracle as bo  # noqa: E402
+from oracle import resnet_oracle as ro  # noqa: E402
+from salve_amd import synthetic  # noqa: E402
+from salve_amd.utils import interpolation_utils as iu  # noqa: E402
+from salve_amd.utils import zorder_utils as zu  # noqa: E402
+
+
+def test_zorder_reference_kats_and_golden(golden_dir):
+    # reference tests/utils/test_zorder_utils.py:8-66
+    cases = [
+        ([[0, 1, 0], [1, 2, 4], [0, 1, 5], [5, 6, 1]], dict(zmin=0, zmax=10, num_slices=5), [False, True, True, True]),
+        ([[0, 1, 0], [1, 2, 4], [2, 3, 5], [3, 4, 1]], dict(zmin=0, zmax=10, num_slices=5), [True, True, True, True]),
+        ([[0, 1, 0], [0, 1, 1], [0, 1, 2], [0, 1, 3]], dict(zmin=0, zmax=10, num_slices=5), [False, False, False, True]),
+        ([[0, 1, 0], [0, 1, 1], [0, 1, 10], [0, 1, 11]], dict(zmin=0, zmax=10, num_slices=5), [False, True, False, False]),
+        ([[0, 1, 0], [0, 1, 1], [0, 1, 2], [0, 1, 3]], dict(zmin=0, zmax=4, num_slices=2), [False, False, False, True]),
+    ]
+    for xyz, kw, exp in cases:
+        a = np.array(xyz)
+        assert zu.choose_elevated_repeated_vals(a[:, 0], a[:, 1], a[:, 2], **kw).tolist() == exp
+    g = np.load(golden_dir / "g2_zorder.npz")
+    for c in range(4):
+        assert np.array_equal(zu.choose_elevated_repeated_vals(g[f"x{c}"], g[f"y{c}"], g[f"z{c}"]), g[f"valid{c}"])
+
+
+def test_remove_hallucinated_content_kat_and_golden(golden_dir):
+    s = np.zeros((6, 6), dtype=np.int64)
+    s[0, 1], s[0, 3], s[2, 1], s[4, 1] = 2, 4, 2, 2
+    sparse = np.stack([s, s, s], -1)
+    interp = np.stack([np.tile(np.arange(1, 7), (6, 1))] * 3, -1)
+    out = iu.remove_hallucinated_content(sparse, interp, K=3)
+    exp = np.array([[1, 2, 3, 4, 5, 0], [1, 2, 3, 4, 5, 0], [1, 2, 3, 0, 0, 0], [1, 2, 3, 0, 0, 0], [1, 2, 3, 0, 0, 0],
+                    [1, 2, 3, 0, 0, 0]], dtype=np.uint8)
+    for c in range(3):
+        assert np.array_equal(out[:, :, c], exp)
+    g = np.load(golden_dir / "g3_mask.npz")
+    assert np.array_equal(iu.remove_hallucinated_content(g["sparse"], g["interp"]), g["out"])
+
+
+def test_interp_dense_grid_from_sparse():
+    # reference tests/utils/test_interpolation_utils.py:8-82
+    col = np.array([[255, 0, 0], [0, 255, 0], [255, 0, 0], [0, 255, 0]])
+    for pts in ([[0, 0], [0, 3], [0, 2], [0, 4]], [[0, 0], [3, 0], [2, 0], [4, 0]], [[1, 1], [5, 5]]):
+        img = np.zeros((10, 10, 3))
+        out = iu.interp_dense_grid_from_sparse(img, np.array(pts), col[: len(pts)], 10, 10, False)
+        assert np.allclose(out, np.zeros((10, 10, 3)))
+    img = np.zeros((4, 4, 3))
+    out = iu.interp_dense_grid_from_sparse(img, np.array([[0, 0], [0, 3], [3, 3], [3, 0]]),
+                                           np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 0, 0]]), 4, 4, False)
+    assert isinstance(out, np.ndarray) and out.shape == (4, 4, 3)
+    rng = np.random.default_rng(0)
+    for G in (40, 131):
+        pts = np.unique(rng.integers(0, G, size=(G * 6, 2)), axis=0)
+        colr = rng.integers(0, 256, size=(pts.shape[0], 3)).astype(np.float64)
+        got = iu.interp_dense_grid_from_sparse(np.zeros((G, G, 3), dtype=np.uint8), pts, colr, G, G, False)
+        assert np.array_equal(got, bo.interp_exact(pts, colr.astype(np.uint8), G, G)[0])
+
+
+def test_config5_large_panos_two_surfaces_resnet152():
+    """2048x1024 panoramas, floor + ceiling, ResNet-152 12-channel early fusion (BASELINE config 5, bf16)."""
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from salve_amd.pipeline import RenderVerifyPipeline
+    from tests.test_gpu_verifier import randomise_bn
+
+    dev = torch.device("cuda:0")
+    H, W = 1024, 2048
+    panos = [synthetic.make_pano(i, H, W) for i in range(2)]
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(152, False, 2, SimpleNamespace(modalities=["ceiling_rgb_texture", "floor_rgb_texture"]))
+    randomise_bn(model)
+    model.eval()
+    pipe = RenderVerifyPipeline(model, dev, pano_hw=(H, W), chunk=4)
+    pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
+    hyp = synthetic.make_hypotheses(3, 2, seed=2)
+    logits = pipe.score(pipe.prepare(hyp)).cpu()
+    torch.cuda.synchronize()
+    bev = pipe.ras.export_u8(pipe.bev[:2]).cpu().numpy()  # hypothesis 0: ceiling, floor of pano i1
+    tiles = []
+    for si, surface in enumerate(("ceiling", "floor")):
+        i1, i2 = int(hyp.i1[0]), int(hyp.i2[0])
+        r1, r2 = bo.render_bev_pair(panos[i1][0], panos[i1][1], panos[i2][0], panos[i2][1], hyp.R[0], hyp.t[0], surface, mode="exact")
+        assert np.array_equal(bev[si], r1["bev"]), surface
+        tiles += [bo.tile_from_bev(r1["bev"]), bo.tile_from_bev(r2["bev"])]
+    got_tiles = pipe.tiles[0].float().cpu().permute(2, 0, 1)
+    exp_tiles = torch.from_numpy(np.concatenate(tiles, 0))
+    assert torch.equal(got_tiles[:12], exp_tiles.bfloat16().float()) and not got_tiles[12:].any()
+    with torch.no_grad():
+        ref = ro.forward(model.state_dict(), 152, [t[None].bfloat16().float() for t in exp_tiles.split(3)])
+    err = float((logits[:1] - ref).abs().max())
+    print(f"config 5: logits {logits[0].tolist()} oracle {ref[0].tolist()} err {err:.2e}")
+    assert err < 3e-2 * max(1.0, float(ref.abs().max()))
