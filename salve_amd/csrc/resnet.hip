@@ -145,7 +145,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < NT; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    // operands swapped: the accumulator is the TRANSPOSED tile, so a lane owns 4 consecutive output
+                    // channels of one output pixel (8 bytes of the NHWC row) instead of 4 pixels of one channel
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -171,18 +173,27 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     }
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-        const int ncol = wc * WN + j * 16 + (lane & 15);
-        const float bias = p.bias[n0 + ncol];
+        const int ncol = wc * WN + j * 16 + 4 * (lane >> 4);  // this lane's 4 consecutive channels of tile column j
+        const float4 bias = *reinterpret_cast<const float4*>(p.bias + n0 + ncol);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int mrow = wr * 64 + i * 16 + (lane >> 4) * 4 + r;
-                float v = acc[i][j][r] + bias;
-                if (p.res) v += bf16_to_f32(Cs[mrow * LDC + ncol]);
-                if (p.relu) v = fmaxf(v, 0.f);
-                Cs[mrow * LDC + ncol] = f32_to_bf16(v);
+            const int mrow = wr * 64 + i * 16 + (lane & 15);
+            uint2* cell = reinterpret_cast<uint2*>(Cs + mrow * LDC + ncol);
+            float v0 = acc[i][j][0] + bias.x, v1 = acc[i][j][1] + bias.y, v2 = acc[i][j][2] + bias.z, v3 = acc[i][j][3] + bias.w;
+            if (p.res) {
+                const uint2 r = *cell;
+                v0 += bf16_to_f32((uint16_t)(r.x & 0xFFFFu));
+                v1 += bf16_to_f32((uint16_t)(r.x >> 16));
+                v2 += bf16_to_f32((uint16_t)(r.y & 0xFFFFu));
+                v3 += bf16_to_f32((uint16_t)(r.y >> 16));
             }
+            if (p.relu) {
+                v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+            }
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+            o.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+            *cell = o;
         }
     }
     __syncthreads();
