@@ -34,6 +34,7 @@ struct SdLocal {
     float hx, hy, hr2;  // stage 0 looks only inside this disc around the edge; a second sweep follows if that was not enough
     uint32_t bits;
     bool upDone, dnDone;
+    bool half;  // the walk started at the neighbour (+1, 0): stop at the first neighbour that precedes s in raster order
 };
 
 // 32 bits of bitmap row y starting at column x0 (may be negative / beyond the image: zeros)
@@ -131,6 +132,10 @@ SD_FN void sdl_begin(SdLocal& s, const SdGrid& g, int sx, int sy) {
     if ((u >> o) & 1u) { nx = 0; ny = 1; }
     if ((c >> (o - 1)) & 1u) { nx = -1; ny = 0; }
     if ((c >> (o + 1)) & 1u) { nx = 1; ny = 0; }
+    // A site only emits the triangles whose other two vertices FOLLOW it in raster order, i.e. lie at angles [0, pi)
+    // counted counter-clockwise from +x.  If the pixel to the right is a site it is the first such neighbour, and the
+    // walk can stop as soon as it reaches a neighbour that precedes s: about half of the star is never computed.
+    s.half = ((c >> (o + 1)) & 1u) != 0;
     if (nx != SDL_NONE) {
         s.n0x = s.ax = nx;
         s.n0y = s.ay = ny;
@@ -252,6 +257,7 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
             if (sd_before(0, 0, s.ax, s.ay) && sd_before(0, 0, s.px, s.py))
                 emit(s.sx, s.sy, s.sx + s.ax, s.sy + s.ay, s.sx + s.px, s.sy + s.py);
             if (s.px == s.n0x && s.py == s.n0y) return SDL_SITE_DONE;
+            if (s.half && !sd_before(0, 0, s.px, s.py)) return SDL_SITE_DONE;  // the rest of the star belongs to other sites
             if (++s.deg > 64) return SDL_SITE_HARD;
             s.ax = s.px;
             s.ay = s.py;
