@@ -296,9 +296,26 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
 // Returns the number of wrap steps, or -1 if the safety bound was hit.
 template <class Emit>
 SD_FN int sd_star(const SdGrid& g, int sx, int sy, Emit& emit) {
+    int steps = 0;
+    // Only triangles whose other two vertices FOLLOW s in raster order are emitted here, i.e. neighbours at angles
+    // [0, pi) counter-clockwise from +x.  If the pixel to the right is a site, it is the first of them (adjacent pixels
+    // are always Delaunay neighbours): walk counter-clockwise from it and stop at the first neighbour that precedes s,
+    // or at the hull.
+    if (sx + 1 < g.W && ((g.occ[sy * g.wpr + ((sx + 1) >> 5)] >> ((sx + 1) & 31)) & 1u)) {
+        int ax = sx + 1, ay = sy;
+        for (;;) {
+            int px, py;
+            if (!sd_apex(g, sx, sy, ax, ay, +1, &px, &py)) break;
+            if (!sd_before(sx, sy, px, py)) break;
+            emit(sx, sy, ax, ay, px, py);
+            if (++steps > SD_MAX_DEGREE) return -1;
+            ax = px;
+            ay = py;
+        }
+        return steps + 1;
+    }
     int n0x, n0y;
     if (!sd_nearest(g, sx, sy, &n0x, &n0y)) return 0;
-    int steps = 0;
     int ax = n0x, ay = n0y;
     bool closed = false;
     for (;;) {  // counter-clockwise from the nearest neighbour
