@@ -72,6 +72,7 @@ SD_FN bool sd_better(int sx, int sy, int ax, int ay, int px, int py, int cx, int
 
 struct SdCircle {
     double ox, oy, r2;
+    double rpad;  // an upper bound of the radius, + 1 pixel (float32 square root, widened): used only to cut sweeps
 };
 
 SD_FN SdCircle sd_circle(int ax, int ay, int bx, int by, int cx, int cy) {
@@ -83,6 +84,7 @@ SD_FN SdCircle sd_circle(int ax, int ay, int bx, int by, int cx, int cy) {
     c.ox = ax + ux;
     c.oy = ay + uy;
     c.r2 = ux * ux + uy * uy;
+    c.rpad = (double)sqrtf((float)c.r2) * (1.0 + 1e-6) + 1.0;
     return c;
 }
 
@@ -156,7 +158,7 @@ SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir
         if (x0 > x1) continue;
         if (*px >= 0) {
             const double dy = y - circ->oy;
-            if (dy * dy > circ->r2 + 2.0 * sqrt(circ->r2) + 1.0) {  // |dy| > r + 1
+            if (dy > circ->rpad || -dy > circ->rpad) {  // |dy| > r + 1
                 if (step > 0 ? dy > 0 : dy < 0) break;             // left the circle for good
                 continue;
             }
@@ -179,8 +181,9 @@ SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir
             if (*px >= 0) {
                 const double dy = y - circ->oy;
                 const double h2 = circ->r2 - dy * dy;
-                // h2 carries a round-off of a few ulp of r^2 (r can reach 2.5e8 px for sliver triangles): widen by it
-                const double half = sqrt((h2 > 0 ? h2 : 0.0) + 4e-15 * circ->r2) + 1.0;
+                // h2 carries a round-off of a few ulp of r^2 (r can reach 2.5e8 px for sliver triangles): widen by it;
+                // a float32 square root (relative error 1e-7, widened as well) is plenty for a superset
+                const double half = (double)sqrtf((float)((h2 > 0 ? h2 : 0.0) + 4e-15 * circ->r2)) * (1.0 + 1e-6) + 1.0;
                 const double lo = floor(circ->ox - half), hi = ceil(circ->ox + half);
                 if (lo > x0) x0 = lo > 1e9 ? g.W : (int)lo;
                 if (hi < x1) x1 = hi < -1e9 ? -1 : (int)hi;
@@ -244,7 +247,7 @@ SD_FN void sd_share_best(const SdGrid& g, int sx, int sy, int ax, int ay, int di
 // strictly on that side, i.e. s->a is a hull edge.
 SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int* outx, int* outy) {
     int px = -1, py = -1, shx = -1, shy = -1;  // shx, shy: the candidate all sharing lanes last agreed on
-    SdCircle circ = {0, 0, 0};
+    SdCircle circ = {0, 0, 0, 0};
     SD_COUNT(apex);
     // 1. a small window around the edge finds the apex in dense regions
     const int M = SD_WINDOW_MARGIN;
@@ -258,7 +261,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
     if (px >= 0) {
         // 2. whatever part of the candidate's circle sticks out of the window (and is on the image) is swept too
-        const double r = sqrt(circ.r2) + 1.0;
+        const double r = circ.rpad;
         const double fy0 = circ.oy - r, fy1 = circ.oy + r, fx0 = circ.ox - r, fx1 = circ.ox + r;
         const int cy0 = fy0 <= 0 ? 0 : (int)fy0, cx0 = fx0 <= 0 ? 0 : (int)fx0;
         const int cy1 = fy1 >= g.H - 1 ? g.H - 1 : (int)fy1 + 1, cx1 = fx1 >= g.W - 1 ? g.W - 1 : (int)fx1 + 1;

@@ -15,6 +15,16 @@
 #pragma once
 #include "star_delaunay.h"
 
+// Square roots and reciprocals below only size search masks and the (conservative) acceptance test, always with a
+// margin that dwarfs one ulp, so the device uses the single-instruction approximations.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SDL_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define SDL_RCP(x) __builtin_amdgcn_rcpf(x)
+#else
+#define SDL_SQRT(x) sqrtf(x)
+#define SDL_RCP(x) (1.0f / (x))
+#endif
+
 #define SDL_ROWS 15      // window rows: sy-7 .. sy+7
 #define SDL_HALF 7
 #define SDL_XLO (-16)    // window columns: sx-16 .. sx+15 (bit = dx + 16)
@@ -31,7 +41,7 @@ struct SdLocal {
     int px, py;        // best apex so far (px == SDL_NONE: none)
     float ux, uy, r2;  // circle through s, a, p (relative to s); for MODE_NEAREST: centre s, r2 = best distance^2
     int mode, k, m, row, deg, stage;
-    float hx, hy, hr2;  // stage 0 looks only inside this disc around the edge; a second sweep follows if that was not enough
+    float hx, hy, hr2, inv_ay;  // stage 0 looks only inside this disc around the edge; a second sweep follows if that was not enough
     uint32_t bits;
     bool upDone, dnDone;
     bool half;  // the walk started at the neighbour (+1, 0): stop at the first neighbour that precedes s in raster order
@@ -77,8 +87,9 @@ SD_FN void sdl_start_query(SdLocal& s, const SdGrid& g, int mode) {
         s.m = (s.ay + (s.ay >= 0 ? 1 : 0)) >> 1;  // a row next to the middle of the edge
         s.hx = 0.5f * (float)s.ax;
         s.hy = 0.5f * (float)s.ay;
-        const float hr = 0.5f * sqrtf((float)(s.ax * s.ax + s.ay * s.ay)) + 2.5f;
+        const float hr = 0.5f * SDL_SQRT((float)(s.ax * s.ax + s.ay * s.ay)) + 2.5f;
         s.hr2 = hr * hr;
+        s.inv_ay = s.ay != 0 ? SDL_RCP((float)s.ay) : 0.f;
         // Unit edges (most edges where the image is densely covered): the apex is a corner of the unit square on the
         // left of s -> a whenever that corner is a site -- the square's circumcircle has no lattice point strictly
         // inside, and a tie between its two left corners is settled by the perturbation.  No sweep needed then.
@@ -169,8 +180,9 @@ SD_FN void sdl_set_apex(SdLocal& s, int cx, int cy) {
     const float ax = (float)s.ax, ay = (float)s.ay, x = (float)cx, y = (float)cy;
     const float d = 2.f * (ax * y - ay * x);  // > 0: c is strictly left of s -> a
     const float a2 = ax * ax + ay * ay, c2 = x * x + y * y;
-    s.ux = (y * a2 - ay * c2) / d;
-    s.uy = (ax * c2 - x * a2) / d;
+    const float inv_d = SDL_RCP(d);
+    s.ux = (y * a2 - ay * c2) * inv_d;
+    s.uy = (ax * c2 - x * a2) * inv_d;
     s.r2 = s.ux * s.ux + s.uy * s.uy;
 }
 
@@ -186,7 +198,7 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
         const bool have = s.px != SDL_NONE;
         const float mx = have ? s.ux : s.hx, my = have ? s.uy : s.hy;
         const float mr2 = have ? s.r2 : (s.stage == 0 ? s.hr2 : 1e9f);
-        const float rad = sqrtf(mr2) + 0.75f;
+        const float rad = SDL_SQRT(mr2) * 1.000001f + 0.75f;
         int r = 0;
         bool found = false;
 #pragma unroll
@@ -208,15 +220,15 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
             const float dy = (float)r - my;
             const float h2 = mr2 - dy * dy;
             // float32 round-off of h2 is a few ulp of r^2: widen by it so that the mask stays a superset
-            const float half = sqrtf((h2 > 0.f ? h2 : 0.f) + 2e-6f * mr2) + 0.75f;
+            const float half = SDL_SQRT((h2 > 0.f ? h2 : 0.f) + 4e-6f * mr2) * 1.000001f + 0.75f;
             int xl = (int)floorf(fmaxf(mx - half, -64.f)), xr = (int)ceilf(fminf(mx + half, 64.f));
             if (s.mode == SDL_MODE_APEX) {  // strictly left of s -> a:  ay * x < ax * y
                 const float t = (float)(s.ax * r);
                 if (s.ay > 0) {
-                    const int b = (int)ceilf(t / (float)s.ay);  // x <= ceil(t/ay) is a superset of x < t/ay
+                    const int b = (int)ceilf(t * s.inv_ay + 0.01f);  // x <= ceil(t/ay) is a superset of x < t/ay
                     if (b < xr) xr = b;
                 } else if (s.ay < 0) {
-                    const int b = (int)floorf(t / (float)s.ay);
+                    const int b = (int)floorf(t * s.inv_ay - 0.01f);
                     if (b > xl) xl = b;
                 } else if (t <= 0.f) {
                     xr = xl - 1;
@@ -239,7 +251,7 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
                 bool enough = false;
                 if (have) {
                     const float dx = s.ux - s.hx, dy = s.uy - s.hy;
-                    const float gap = sqrtf(s.hr2) - sqrtf(s.r2) - 0.3f;
+                    const float gap = SDL_SQRT(s.hr2) - SDL_SQRT(s.r2) - 0.3f;
                     enough = gap > 0.f && dx * dx + dy * dy < gap * gap;
                 }
                 if (!enough) {
@@ -249,7 +261,7 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
                 }
             }
             if (!have) return SDL_SITE_HARD;  // nothing in the window (hull edge, or a far apex)
-            const float rr = sqrtf(s.r2) + 0.26f;
+            const float rr = SDL_SQRT(s.r2) * 1.000001f + 0.26f;
             if (s.ux - rr < (float)SDL_XLO || s.ux + rr > (float)SDL_XHI || s.uy - rr < (float)-SDL_HALF ||
                 s.uy + rr > (float)SDL_HALF)
                 return SDL_SITE_HARD;  // the circle leaves the window: not certified
