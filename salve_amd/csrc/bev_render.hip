@@ -406,22 +406,35 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
         RasterEmit raster = {H, W, wpr, occ, msk, keys, bev, (c.out_flags & 1) ? -1 : H - 1, 0, 1, (c.dbg_flags & 2) != 0};
         QueueEmit qemit = {triq, &scal[8], H * W, raster};
         SdLocal st;
-        bool active = false;
+        bool active = false, exhausted = false;
         int iters = 0;
         for (;;) {
-            if (!active) {
-                const int i = atomicAdd(&scal[6], 1);
-                if (i >= nsites) break;
-                const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sdl_begin(st, g, (int)(s & 0xFFFFu), (int)(s >> 16));
-                active = true;
-                if (dbg_stats) { atomicAdd(&scal[9], 1); atomicAdd(&scal[10], (int)(s & 0xFFFFu) + (int)(s >> 16)); }
+            // Idle lanes are refilled in batches: the (long) site set-up code is then issued once per ~16 finished sites
+            // instead of in nearly every iteration, at the price of a few lane-iterations of idling.
+            const unsigned long long idle = __ballot(!active && !exhausted);
+            const unsigned long long busy = __ballot(active);
+            if (idle != 0ull && (__popcll(idle) >= 16 || busy == 0ull)) {
+                if (!active && !exhausted) {
+                    const int i = atomicAdd(&scal[6], 1);
+                    if (i >= nsites) {
+                        exhausted = true;
+                    } else {
+                        const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sdl_begin(st, g, (int)(s & 0xFFFFu), (int)(s >> 16));
+                        active = true;
+                        if (dbg_stats) { atomicAdd(&scal[9], 1); atomicAdd(&scal[10], (int)(s & 0xFFFFu) + (int)(s >> 16)); }
+                    }
+                }
+            } else if (busy == 0ull) {
+                break;  // every lane is exhausted and idle
             }
-            const int r = sdl_iter(st, g, qemit);
-            iters++;
-            if (r != SDL_CONTINUE) {
-                active = false;
-                if (r == SDL_SITE_HARD) __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (active) {
+                const int r = sdl_iter(st, g, qemit);
+                iters++;
+                if (r != SDL_CONTINUE) {
+                    active = false;
+                    if (r == SDL_SITE_HARD) __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         if (dbg_stats) atomicAdd(&scal[4], iters);
