@@ -27,6 +27,10 @@ import torch
 PANO_H, PANO_W, CROP = 512, 1024, 80
 BYTES_PER_RENDER = (PANO_H - 2 * CROP) * PANO_W * (3 + 2) + 501 * 501 * 3  # RGB u8 + depth u16 read, BEV u8 written
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# HBM bytes of one bev_densify_kernel launch of 512 renders from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate
+# passes, KiB units; profiles/r01_pmc_traffic.md).  The kernel reads 8 B / lane, for which FETCH_SIZE is uncalibrated:
+# the read side is taken as counted (lower bound).
+DENSIFY_TRAFFIC_BYTES_512 = (1382642 + 1509295) * 1024
 
 
 def cpu_baseline(n_hyp: int, procs: int):
@@ -140,14 +144,15 @@ def main() -> None:
                        "hypotheses_per_gpu": args.hyps, "panos": args.panos, "renders_per_hypothesis": 1,
                        "cached_identity_renders": args.panos, "chunk": args.chunk, "parallelism": f"hypothesis-shard x{world}"},
             "roofline": {"kernel": "bev_densify_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": DENSIFY_TRAFFIC_BYTES_512 if renders == 512 else None,
                          "launch_ms": round(dens_ms, 3), "renders_per_launch": renders, "algorithmic_bytes_per_render": BYTES_PER_RENDER},
         }
         if world == 1 and not args.no_cpu_baseline:
             procs = min(os.cpu_count() or 1, 8)
-            v, secs = cpu_baseline(3 * procs, procs)
+            v, secs = cpu_baseline(6 * procs, procs)
             out["cpu_baseline"] = {"value": round(v, 4), "unit": "hypotheses/s", "cores": procs, "kind": "port",
-                                   "sample": f"{3 * procs} hypotheses of the same table (2 renders + ResNet-50 fp32 each), oracle scipy mode, "
+                                   "sample": f"{6 * procs} hypotheses of the same table (2 renders + ResNet-50 fp32 each), oracle scipy mode, "
                                              f"{procs} processes, {secs:.1f} s"}
         print(json.dumps(out), flush=True)
     if world > 1:
