@@ -221,13 +221,31 @@ SD_FN void sd_share_best(const SdGrid& g, int sx, int sy, int ax, int ay, int di
     if (g.nlanes > 1) {
         // nothing to merge if no lane improved on the candidate all lanes agreed on last time (the common case for
         // sweeps outside the window)
-        if (!__any(*px != *shared_x || *py != *shared_y)) return;
-        for (int off = 32; off >= 1; off >>= 1) {
-            const int ox = __shfl_xor(*px, off), oy = __shfl_xor(*py, off);
-            const bool differs = ox >= 0 && (ox != *px || oy != *py);
-            if (differs && (*px < 0 || sd_better(sx, sy, ax, ay, *px, *py, ox, oy, dir))) {
-                *px = ox;
-                *py = oy;
+        const unsigned long long changed = __ballot(*px >= 0 && (*px != *shared_x || *py != *shared_y));
+        if (changed == 0ull) return;
+        if (__popcll(changed) <= 8) {
+            // few lanes found something: fold them in one after the other (wave-uniform, no shuffles)
+            int bx = *shared_x, by = *shared_y;
+            unsigned long long m = changed;
+            while (m) {
+                const int l = (int)__ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const int ox = __builtin_amdgcn_readlane(*px, l), oy = __builtin_amdgcn_readlane(*py, l);
+                if ((ox != bx || oy != by) && (bx < 0 || sd_better(sx, sy, ax, ay, bx, by, ox, oy, dir))) {
+                    bx = ox;
+                    by = oy;
+                }
+            }
+            *px = bx;
+            *py = by;
+        } else {
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int ox = __shfl_xor(*px, off), oy = __shfl_xor(*py, off);
+                const bool differs = ox >= 0 && (ox != *px || oy != *py);
+                if (differs && (*px < 0 || sd_better(sx, sy, ax, ay, *px, *py, ox, oy, dir))) {
+                    *px = ox;
+                    *py = oy;
+                }
             }
         }
         if (*px >= 0) *circ = sd_circle(sx, sy, ax, ay, *px, *py);
