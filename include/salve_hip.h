@@ -197,6 +197,10 @@ size_t salve_resnet_workspace_bytes(void* handle, int32_t batch);
 int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* logits, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* Development aid (not part of the hot path): a synthetic load kernel -- mode 0 MFMA only, 1 VALU only, 2 LDS reads only,
+ * 3 MFMA + LDS -- used by tools/debug_overlap2.py to study co-residency with the rasteriser. */
+int salve_debug_burn(int32_t blocks, int32_t iters, int32_t mode, float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

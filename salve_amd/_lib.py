@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "salve_resnet_workspace_bytes",
     "salve_resnet_forward",
     "salve_resnet_num_layers",
+    "salve_debug_burn",
 )
 
 
@@ -113,6 +114,8 @@ def load() -> ctypes.CDLL:
     lib.salve_resnet_forward.restype = ctypes.c_int
     lib.salve_resnet_num_layers.argtypes = [vp]
     lib.salve_resnet_num_layers.restype = ctypes.c_int
+    lib.salve_debug_burn.argtypes = [i32, i32, i32, vp, vp]
+    lib.salve_debug_burn.restype = ctypes.c_int
     _lib = lib
     return lib
 

@@ -263,7 +263,7 @@ __device__ __forceinline__ unsigned long long load_key(const unsigned long long*
 __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     DevCfg c, const unsigned long long* __restrict__ keys_all, uint32_t* __restrict__ bev_all,
     uint32_t* __restrict__ sitelist_all, uint32_t* __restrict__ hardlist_all, unsigned long long* __restrict__ triq_all,
-    uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats) {
+    uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats, int16_t* __restrict__ dbg_aux) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = c.H, W = c.W, wpr = c.wpr;
     uint32_t* occ = reinterpret_cast<uint32_t*>(smem);
@@ -433,6 +433,11 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
                 iters++;
                 if (r != SDL_CONTINUE) {
                     active = false;
+                    if (dbg_mask && (c.dbg_flags & 16))  // development: how each site's local walk ended
+                    {
+                        dbg_mask[((size_t)rid * H + st.sy) * W + st.sx] = (uint8_t)((r == SDL_SITE_HARD ? 200 : 100) + min(st.deg, 50));
+                        if (dbg_aux) { int16_t* o = dbg_aux + ((size_t)rid * c.npts + (size_t)st.sy * W + st.sx) * 2; o[0] = (int16_t)(st.dbg_hash & 0xFFFF); o[1] = (int16_t)(st.dbg_hash >> 16); }
+                    }
                     if (r == SDL_SITE_HARD) __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -668,7 +673,7 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
             attr_lds = lds;
         }
         hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, keys, out_bev, sitelist, hardlist, triq,
-                           dbg_mask, dbg_stats);
+                           dbg_mask, dbg_stats, (d.dbg_flags & 16) ? dbg_img_xy : nullptr);
         SALVE_HIP_CHECK(hipGetLastError());
         if (dbg_keys) SALVE_HIP_CHECK(hipMemcpyAsync(dbg_keys, keys, (size_t)n * npx * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     }

@@ -85,6 +85,30 @@ def test_render_matches_oracle_bit_for_bit(setup):
         assert diff.sum() == 0, f"render {k}: {diff.sum()} BEV pixels differ"
 
 
+def test_many_poses_final_image_bit_exact():
+    """24 renders (4 panoramas, both surfaces, random poses incl. far translations that clip the cloud at the window):
+    final BEV image against the oracle, bit for bit."""
+    dev = torch.device("cuda:0")
+    ras = BevRasteriser(dev)
+    panos = [synthetic.make_pano(i) for i in range(10, 14)]
+    d_rgb, d_depth = ras.upload_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
+    hyp = synthetic.make_hypotheses(24, 4, seed=7)
+    hyp.t[::5] *= 2.2  # push some clouds half out of the window
+    surf = np.arange(24) % 2
+    h = pack_hypotheses(hyp.i1, surf, hyp.R, hyp.t, np.ones(24))
+    bev, dbg = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), 24, debug=True)
+    torch.cuda.synchronize()
+    got = ras.export_u8(bev).cpu().numpy()
+    assert not dbg.stats[:, 5].any()
+    for k in range(24):
+        res, _ = oracle_render(panos, int(hyp.i1[k]), "floor" if surf[k] == 0 else "ceiling", hyp.R[k], hyp.t[k], 1)
+        if res is None:
+            assert not got[k].any()
+            continue
+        assert int(dbg.stats[k, 0]) == int(res["valid"].sum())
+        assert np.array_equal(got[k], res["bev"]), f"render {k}"
+
+
 def test_tiles_match_oracle(setup):
     ras, panos, d_rgb, d_depth, hyp = setup
     h = pack_hypotheses([0, 1], [0, 1], hyp.R[:2], hyp.t[:2], [1, 0])
