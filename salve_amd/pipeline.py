@@ -43,7 +43,7 @@ def surfaces_for(modalities: Sequence[str]) -> List[str]:
 
 class RenderVerifyPipeline:
     def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: int = 512,
-                 overlap: bool = False) -> None:
+                 overlap: bool = True) -> None:
         self.device = torch.device(device)
         self.model = model
         self.surfaces = surfaces_for(model.modalities)
@@ -52,10 +52,9 @@ class RenderVerifyPipeline:
         self.chunk = chunk
         S = len(self.surfaces)
         Hb, Wb = self.ras.bev_hw
-        # overlap=True: two sets of chunk buffers, the rasteriser fills one on its own HIP stream while the verifier
-        # consumes the other.  OFF by default: with 2 x 66 KB of LDS per CU the densify workgroups leave no room for
-        # the convolution blocks, so nothing is gained today, and co-residency of bev_densify_kernel with
-        # conv_igemm_kernel on a CU was observed to perturb a few pixels per 64 renders
+        # overlap=True: two sets of chunk buffers -- the rasteriser (VALU / LDS-latency bound) fills one on its own HIP
+        # stream while the verifier (MFMA / HBM bound) consumes the other, so the tail of one launch runs under the other
+        # kernel.  (Requires the library to be built without SLP-packed fp32: DESIGN.md section 8.)
         self.nbuf = 2 if overlap else 1
         self.bevs = [torch.empty((chunk * S, Hb, Wb), dtype=torch.int32, device=self.device) for _ in range(self.nbuf)]
         # tiles: bf16 NHWC, pad channels (never written) stay zero

@@ -105,7 +105,7 @@ def test_full_size_properties():
     panos = [synthetic.make_pano(i) for i in range(P)]
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
-    pipe = RenderVerifyPipeline(model, dev, chunk=64)  # serial streams (default)
+    pipe = RenderVerifyPipeline(model, dev, chunk=64)  # two HIP streams (default)
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     table = synthetic.make_hypotheses(N, P, seed=1)
     # identity pose through the posed branch == the cached identity render
@@ -118,7 +118,7 @@ def test_full_size_properties():
     torch.cuda.synchronize()
     assert torch.equal(a, b)  # deterministic
     assert torch.isfinite(a).all()
-    pipe2 = RenderVerifyPipeline(model, dev, chunk=32)
+    pipe2 = RenderVerifyPipeline(model, dev, chunk=32, overlap=False)  # one stream, other batching
     pipe2.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     c = pipe2.score(pipe2.prepare(table))
     torch.cuda.synchronize()
