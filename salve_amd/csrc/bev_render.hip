@@ -436,7 +436,6 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
                     if (dbg_mask && (c.dbg_flags & 16))  // development: how each site's local walk ended
                     {
                         dbg_mask[((size_t)rid * H + st.sy) * W + st.sx] = (uint8_t)((r == SDL_SITE_HARD ? 200 : 100) + min(st.deg, 50));
-                        if (dbg_aux) { int16_t* o = dbg_aux + ((size_t)rid * c.npts + (size_t)st.sy * W + st.sx) * 2; o[0] = (int16_t)(st.dbg_hash & 0xFFFF); o[1] = (int16_t)(st.dbg_hash >> 16); }
                     }
                     if (r == SDL_SITE_HARD) __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }

@@ -44,7 +44,6 @@ struct SdLocal {
     float hx, hy, hr2, inv_ay;  // stage 0 looks only inside this disc around the edge; a second sweep follows if that was not enough
     uint32_t bits;
     bool upDone, dnDone;
-    uint32_t dbg_hash;  // development: hash of every bitmap word this walk has read
     bool half;  // the walk started at the neighbour (+1, 0): stop at the first neighbour that precedes s in raster order
 };
 
@@ -131,7 +130,6 @@ SD_FN void sdl_begin(SdLocal& s, const SdGrid& g, int sx, int sy) {
     s.sx = sx;
     s.sy = sy;
     s.deg = 0;
-    s.dbg_hash = 0;
     s.ax = s.ay = 0;
     // an 8-neighbour, if there is one, is a nearest site (distance 1 before sqrt 2) and needs no search
     const uint32_t c = sdl_row32(g, sy, sx + SDL_XLO), u = sdl_row32(g, sy + 1, sx + SDL_XLO), d = sdl_row32(g, sy - 1, sx + SDL_XLO);
@@ -238,9 +236,7 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
             }
             s.row = r;
             // the window row straight from the LDS bitmap (the site itself is not a candidate)
-            const uint32_t roww_ = sdl_row32(g, s.sy + r, s.sx + SDL_XLO);
-            s.dbg_hash = (s.dbg_hash * 31u) ^ roww_ ^ ((uint32_t)(r + 8) << 24);
-            s.bits = roww_ & sdl_range_mask(xl, xr) & (r == 0 ? ~(1u << (0 - SDL_XLO)) : 0xFFFFFFFFu);
+            s.bits = sdl_row32(g, s.sy + r, s.sx + SDL_XLO) & sdl_range_mask(xl, xr) & (r == 0 ? ~(1u << (0 - SDL_XLO)) : 0xFFFFFFFFu);
         } else if (s.upDone && s.dnDone) {
             // ---- sweep finished
             if (s.mode == SDL_MODE_NEAREST) {
