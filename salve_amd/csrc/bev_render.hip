@@ -23,6 +23,12 @@
 #include <string.h>
 
 #include "../../include/salve_hip.h"
+#if defined(SALVE_PROFILE_WALK)
+// development build: count the general walk's work in LDS (read back through dbg_stats slots 1, 2, 3)
+enum { SDC_apex = 0, SDC_apex_slow, SDC_apex_far, SDC_rows, SDC_bits, SDC_exact, SDC_N };
+__shared__ int sd_counters[SDC_N];
+#define SD_COUNT(c) atomicAdd(&sd_counters[SDC_##c], 1)
+#endif
 #include "star_delaunay.h"
 #include "star_local.h"
 #include "salve_common.h"
@@ -282,6 +288,9 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = DENSIFY_THREADS >> 6;
     const int p = c.mask_half;
 
+#if defined(SALVE_PROFILE_WALK)
+    if (tid < SDC_N) sd_counters[tid] = 0;
+#endif
     if (tid < 12) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : 0);  // [6] site cursor [7] hard sites [8] queued triangles
     __syncthreads();
 
@@ -469,7 +478,11 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     }
     if (dbg_stats) {
         __syncthreads();
+#if defined(SALVE_PROFILE_WALK)
+        if (tid < 8) dbg_stats[rid * 8 + tid] = tid < 6 ? sd_counters[tid] : scal[tid + 1];
+#else
         if (tid < 8) dbg_stats[rid * 8 + tid] = tid == 1 ? scal[9] : (tid == 2 ? scal[10] : (tid < 6 ? scal[tid] : scal[tid + 1]));  // [1] sites begun [2] checksum [6] hard sites [7] queued triangles
+#endif
     }
 }
 

@@ -145,12 +145,23 @@ SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
 // circle (supersets with a safety margin), so rows on the wrong side cost a few instructions and the work shrinks
 // as the apex improves.  A sweep stops once it has left the circle in its direction of travel.  Every surviving
 // bit is tested with the exact predicates.
-SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int ya, int yb, int step, int xa,
-                        int xb, int* px, int* py, SdCircle* circ) {
+struct SdEdge {
+    // dir * orient(s, a, (x, y)) = P (y - sy) - Q (x - sx) >= 1  <=>  strictly on side dir of s -> a.
+    // Small integers (< 2^11), so float32 products are exact; only the quotient is rounded, and the cut keeps a margin.
+    float P, Q, invQ;
+};
+
+SD_FN SdEdge sd_edge(int sx, int sy, int ax, int ay, int dir) {
+    SdEdge e;
+    e.P = (float)(dir * (ax - sx));
+    e.Q = (float)(dir * (ay - sy));
+    e.invQ = e.Q != 0.f ? 1.0f / e.Q : 0.f;
+    return e;
+}
+
+SD_FN void sd_scan_rows(const SdGrid& g, const SdEdge& e, int sx, int sy, int ax, int ay, int dir, int ya, int yb, int step,
+                        int xa, int xb, int* px, int* py, SdCircle* circ) {
     const bool wide = xb - xa > 48;
-    // dir * orient(s, a, (x, y)) = P (y - sy) - Q (x - sx) >= 1
-    const double P = (double)(dir * (ax - sx)), Q = (double)(dir * (ay - sy));
-    const double invQ = Q != 0.0 ? 1.0 / Q : 0.0;
     for (int y = ya + g.lane * step; step > 0 ? y <= yb : y >= yb; y += g.nlanes * step) {
         SD_COUNT(rows);
         int x0 = xa > g.rmin[y] ? xa : g.rmin[y];
@@ -164,17 +175,17 @@ SD_FN void sd_scan_rows(const SdGrid& g, int sx, int sy, int ax, int ay, int dir
             }
         }
         if (wide) {
-            const double T = P * (double)(y - sy) - 1.0;
-            if (Q == 0.0) {
-                if (T < 0.0) continue;
+            const float T = e.P * (float)(y - sy) - 1.0f;  // exact
+            if (e.Q == 0.f) {
+                if (T < 0.f) continue;
             } else {
-                const double t = T * invQ;  // Q u <= T  with u = x - sx
-                if (Q > 0.0) {
-                    const double hi = floor(t) + 1.0 + sx;
-                    if (hi < x1) x1 = hi < -1.0 ? -1 : (int)hi;
+                const float t = T * e.invQ;  // Q u <= T  with u = x - sx ; |t| < 2^22, rounding error < 1
+                if (e.Q > 0.f) {
+                    const float hi = floorf(t) + 2.0f + (float)sx;
+                    if (hi < (float)x1) x1 = hi < -1.0f ? -1 : (int)hi;
                 } else {
-                    const double lo = ceil(t) - 1.0 + sx;
-                    if (lo > x0) x0 = lo > 1e9 ? g.W : (int)lo;
+                    const float lo = ceilf(t) - 2.0f + (float)sx;
+                    if (lo > (float)x0) x0 = lo > 1e9f ? g.W : (int)lo;
                 }
                 if (x0 > x1) continue;
             }
@@ -266,6 +277,7 @@ SD_FN void sd_share_best(const SdGrid& g, int sx, int sy, int ax, int ay, int di
 SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int* outx, int* outy) {
     int px = -1, py = -1, shx = -1, shy = -1;  // shx, shy: the candidate all sharing lanes last agreed on
     SdCircle circ = {0, 0, 0, 0};
+    const SdEdge edge = sd_edge(sx, sy, ax, ay, dir);
     SD_COUNT(apex);
     // 1. a small window around the edge finds the apex in dense regions
     const int M = SD_WINDOW_MARGIN;
@@ -275,7 +287,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     if (wx0 < 0) wx0 = 0;
     if (wy1 > g.H - 1) wy1 = g.H - 1;
     if (wx1 > g.W - 1) wx1 = g.W - 1;
-    sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, wx0, wx1, &px, &py, &circ);
+    sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0, wy1, 1, wx0, wx1, &px, &py, &circ);
     sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
     if (px >= 0) {
         // 2. whatever part of the candidate's circle sticks out of the window (and is on the image) is swept too
@@ -285,24 +297,24 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         const int cy1 = fy1 >= g.H - 1 ? g.H - 1 : (int)fy1 + 1, cx1 = fx1 >= g.W - 1 ? g.W - 1 : (int)fx1 + 1;
         if (cy1 > wy1 || cy0 < wy0 || cx0 < wx0 || cx1 > wx1) {
             SD_COUNT(apex_slow);
-            if (cy1 > wy1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy1 + 1, cy1, 1, cx0, cx1, &px, &py, &circ);
+            if (cy1 > wy1) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy1 + 1, cy1, 1, cx0, cx1, &px, &py, &circ);
             sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
-            if (cy0 < wy0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0 - 1, cy0, -1, cx0, cx1, &px, &py, &circ);
+            if (cy0 < wy0) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0 - 1, cy0, -1, cx0, cx1, &px, &py, &circ);
             const int ry0 = cy0 > wy0 ? cy0 : wy0, ry1 = cy1 < wy1 ? cy1 : wy1;
-            if (cx0 < wx0) sd_scan_rows(g, sx, sy, ax, ay, dir, ry0, ry1, 1, cx0, wx0 - 1, &px, &py, &circ);
-            if (cx1 > wx1) sd_scan_rows(g, sx, sy, ax, ay, dir, ry0, ry1, 1, wx1 + 1, cx1, &px, &py, &circ);
+            if (cx0 < wx0) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, ry0, ry1, 1, cx0, wx0 - 1, &px, &py, &circ);
+            if (cx1 > wx1) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, ry0, ry1, 1, wx1 + 1, cx1, &px, &py, &circ);
             sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
         }
     } else {
         // 3. nothing near the edge: the window's rows outside its columns, then away from the window downwards
         //    and upwards.  An empty result means s->a is a hull edge.
         SD_COUNT(apex_far);
-        if (wx0 > 0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, 0, wx0 - 1, &px, &py, &circ);
-        if (wx1 < g.W - 1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0, wy1, 1, wx1 + 1, g.W - 1, &px, &py, &circ);
+        if (wx0 > 0) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0, wy1, 1, 0, wx0 - 1, &px, &py, &circ);
+        if (wx1 < g.W - 1) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0, wy1, 1, wx1 + 1, g.W - 1, &px, &py, &circ);
         sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
-        if (wy1 < g.H - 1) sd_scan_rows(g, sx, sy, ax, ay, dir, wy1 + 1, g.H - 1, 1, 0, g.W - 1, &px, &py, &circ);
+        if (wy1 < g.H - 1) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy1 + 1, g.H - 1, 1, 0, g.W - 1, &px, &py, &circ);
         sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
-        if (wy0 > 0) sd_scan_rows(g, sx, sy, ax, ay, dir, wy0 - 1, 0, -1, 0, g.W - 1, &px, &py, &circ);
+        if (wy0 > 0) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0 - 1, 0, -1, 0, g.W - 1, &px, &py, &circ);
         sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
     }
     *outx = px;

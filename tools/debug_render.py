@@ -21,7 +21,7 @@ st = dbg.stats.cpu().numpy()
 print("mean stats [sites, begun, -, rows, iters, err, hard, queued]:", st.mean(0).round(0).tolist())
 res = {}
 for rnd in range(3):
-    for flags in (0, 4, 12, 1):
+    for flags in (0, 4, 12, 1, 2, 6):
         ras.cfg.reserved1 = flags
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -32,4 +32,5 @@ for rnd in range(3):
 ras.cfg.reserved1 = 0
 print("ms per render (min of 3 rounds):", {k: round(min(v), 5) for k, v in res.items()})
 a, b, c, d = (min(res[k]) for k in (0, 4, 12, 1))
+print(f"  hard-site walk without its rasterisation: {(min(res[2]) - min(res[6]))*1e3:.1f} us")
 print(f"  scatter+bitmaps+mask+base {d*1e3:.1f} us | local walk {(c-d)*1e3:.1f} us | raster {(b-c)*1e3:.1f} us | hard sites {(a-b)*1e3:.1f} us | total {a*1e3:.1f} us")
