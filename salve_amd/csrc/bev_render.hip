@@ -25,12 +25,14 @@
 #include "../../include/salve_hip.h"
 #if defined(SALVE_PROFILE_WALK)
 // development build: count the general walk's work in LDS (read back through dbg_stats slots 1, 2, 3)
-enum { SDC_apex = 0, SDC_apex_slow, SDC_apex_far, SDC_rows, SDC_bits, SDC_exact, SDC_N };
+enum { SDC_apex = 0, SDC_apex_slow, SDC_apex_far, SDC_rows, SDC_bits, SDC_exact, SDC_apex_table, SDC_N };
 __shared__ int sd_counters[SDC_N];
 #define SD_COUNT(c) atomicAdd(&sd_counters[SDC_##c], 1)
 #endif
 #include "star_delaunay.h"
 #include "star_local.h"
+#include "star_table.h"
+#include <mutex>
 #include "salve_common.h"
 
 namespace {
@@ -266,6 +268,25 @@ __device__ __forceinline__ unsigned long long load_key(const unsigned long long*
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Apex candidates of short edges (star_table.h): built once per process on the host with the exact predicates.
+__device__ SdTable d_star_table;
+
+static int ensure_star_table() {
+    static std::mutex mu;
+    static unsigned long long uploaded = 0;  // bit per device ordinal
+    static SdTable host_table;
+    static int built = 0;                    // 0 not yet, 1 ok, -1 failed
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    SALVE_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && ((uploaded >> dev) & 1ull)) return SALVE_OK;
+    if (built == 0) built = sdt_build(&host_table) ? 1 : -1;
+    if (built < 0) { salve_fail("star table construction could not be certified"); return SALVE_ERR_UNSUPPORTED; }
+    SALVE_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_star_table), &host_table, sizeof(SdTable)));
+    if (dev >= 0 && dev < 64) uploaded |= 1ull << dev;
+    return SALVE_OK;
+}
+
 __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     DevCfg c, const unsigned long long* __restrict__ keys_all, uint32_t* __restrict__ bev_all,
     uint32_t* __restrict__ sitelist_all, uint32_t* __restrict__ hardlist_all, unsigned long long* __restrict__ triq_all,
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     //      E2: hard sites (hull, sparse regions: a few %) walk their star with the general algorithm and rasterise
     //          in place.   F: all lanes rasterise the queued triangles.
     if (!degenerate && !(c.dbg_flags & 1)) {
-        SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1};
+        SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0]};
         RasterEmit raster = {H, W, wpr, occ, msk, keys, bev, (c.out_flags & 1) ? -1 : H - 1, 0, 1, (c.dbg_flags & 2) != 0};
         QueueEmit qemit = {triq, &scal[8], H * W, raster};
         SdLocal st;
@@ -678,6 +699,8 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         SALVE_HIP_CHECK(hipGetLastError());
     }
     if (densify) {
+        const int tab_status = ensure_star_table();
+        if (tab_status != SALVE_OK) return tab_status;
         static size_t attr_lds = 0;
         if (lds > attr_lds) {  // opt in to more than 64 KB of dynamic LDS, for exactly what this launch uses
             SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel),

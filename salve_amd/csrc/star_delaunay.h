@@ -34,7 +34,27 @@ struct SdGrid {
     // Row sweeps can be shared by the lanes of a wavefront that all work on the SAME site: this caller then visits
     // rows lane, lane + nlanes, ... of every sweep and the lanes merge their candidates (sd_share_best).
     int lane, nlanes;     // 0, 1 for a caller that sweeps alone
+    const int8_t* tab;    // SdTable (star_table.h) or nullptr: apex candidates of short edges, best first
 };
+
+// Table of apex candidates for short edges (built by star_table.h): for the edge vector (ax, ay) from the origin, the
+// lattice points strictly left of the edge in the order in which a circle through the edge's end points, grown to the
+// left, meets them (ties by the perturbation).  The first occupied one is the apex.
+#define SDT_AMAX 5                                   // edge vectors with |ax|, |ay| <= SDT_AMAX
+#define SDT_SIDE (2 * SDT_AMAX + 1)
+#define SDT_NVEC (SDT_SIDE * SDT_SIDE)
+#define SDT_LEN 32                                   // candidates kept per vector
+#define SDT_REACH 48                                 // search radius when building (must dwarf the kept candidates)
+
+struct SdTable {
+    int8_t off[SDT_NVEC][SDT_LEN][2];  // (dx, dy) relative to the edge's origin, best first
+};
+
+SD_FN int sdt_index(int ax, int ay) { return (ay + SDT_AMAX) * SDT_SIDE + (ax + SDT_AMAX); }
+
+SD_FN bool sd_occupied(const SdGrid& g, int x, int y) {
+    return x >= 0 && x < g.W && y >= 0 && y < g.H && ((g.occ[y * g.wpr + (x >> 5)] >> (x & 31)) & 1u);
+}
 
 SD_FN int32_t sd_orient(int ax, int ay, int bx, int by, int cx, int cy) {
     return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
@@ -279,6 +299,34 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     SdCircle circ = {0, 0, 0, 0};
     const SdEdge edge = sd_edge(sx, sy, ax, ay, dir);
     SD_COUNT(apex);
+    // 0. short edge: the pre-sorted candidate table answers with bitmap probes alone.  (Side -1 of s->a is side +1 of
+    //    a->s, so the table is entered with the edge reversed.)
+    if (g.tab != nullptr) {
+        const int ox = dir > 0 ? sx : ax, oy = dir > 0 ? sy : ay;
+        const int vx = dir > 0 ? ax - sx : sx - ax, vy = dir > 0 ? ay - sy : sy - ay;
+        if (vx >= -SDT_AMAX && vx <= SDT_AMAX && vy >= -SDT_AMAX && vy <= SDT_AMAX) {
+            const int8_t* row = g.tab + sdt_index(vx, vy) * (SDT_LEN * 2);
+            int hit = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (g.nlanes == 64) {  // one candidate per lane, the lowest occupied entry wins
+                const int k = g.lane & (SDT_LEN - 1);
+                const bool b = g.lane < SDT_LEN && sd_occupied(g, ox + row[2 * k], oy + row[2 * k + 1]);
+                const unsigned long long m = __ballot(b);
+                if (m) hit = (int)__ffsll((long long)m) - 1;
+            } else
+#endif
+            {
+                for (int k = 0; k < SDT_LEN && hit < 0; k++)
+                    if (sd_occupied(g, ox + row[2 * k], oy + row[2 * k + 1])) hit = k;
+            }
+            if (hit >= 0) {
+                SD_COUNT(apex_table);
+                *outx = ox + row[2 * hit];
+                *outy = oy + row[2 * hit + 1];
+                return true;
+            }
+        }
+    }
     // 1. a small window around the edge finds the apex in dense regions
     const int M = SD_WINDOW_MARGIN;
     int wy0 = (sy < ay ? sy : ay) - M, wy1 = (sy > ay ? sy : ay) + M;

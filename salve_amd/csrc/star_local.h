@@ -14,6 +14,7 @@
 // The symbolic perturbation (raster order of the sites) is the one of star_delaunay.h.
 #pragma once
 #include "star_delaunay.h"
+#include "star_table.h"
 
 // Square roots and reciprocals below only size search masks and the (conservative) acceptance test, always with a
 // margin that dwarfs one ulp, so the device uses the single-instruction approximations.
@@ -44,6 +45,7 @@ struct SdLocal {
     float hx, hy, hr2, inv_ay;  // stage 0 looks only inside this disc around the edge; a second sweep follows if that was not enough
     uint32_t bits;
     bool upDone, dnDone;
+    bool cert;  // the apex came from the table (star_table.h): exact and complete by construction, no circle test needed
     bool half;  // the walk started at the neighbour (+1, 0): stop at the first neighbour that precedes s in raster order
 };
 
@@ -82,6 +84,7 @@ SD_FN void sdl_start_query(SdLocal& s, const SdGrid& g, int mode) {
     s.px = SDL_NONE;
     s.py = 0;
     s.stage = 0;
+    s.cert = false;
     sdl_restart_scan(s);
     if (mode == SDL_MODE_APEX) {
         s.m = (s.ay + (s.ay >= 0 ? 1 : 0)) >> 1;  // a row next to the middle of the edge
@@ -90,31 +93,24 @@ SD_FN void sdl_start_query(SdLocal& s, const SdGrid& g, int mode) {
         const float hr = 0.5f * SDL_SQRT((float)(s.ax * s.ax + s.ay * s.ay)) + 2.5f;
         s.hr2 = hr * hr;
         s.inv_ay = s.ay != 0 ? SDL_RCP((float)s.ay) : 0.f;
-        // Unit edges (most edges where the image is densely covered): the apex is a corner of the unit square on the
-        // left of s -> a whenever that corner is a site -- the square's circumcircle has no lattice point strictly
-        // inside, and a tie between its two left corners is settled by the perturbation.  No sweep needed then.
-        if (s.ax >= -1 && s.ax <= 1 && s.ay >= -1 && s.ay <= 1) {
-            const int nx = -s.ay, ny = s.ax;  // left normal
-            int cx = SDL_NONE, cy = 0;
-            if (s.ax == 0 || s.ay == 0) {
-                const bool b1 = sdl_bit(g, s.sx + nx, s.sy + ny), b2 = sdl_bit(g, s.sx + s.ax + nx, s.sy + s.ay + ny);
-                if (b1 && b2) {
-                    const bool second = sdl_inside(s.ax, s.ay, nx, ny, s.ax + nx, s.ay + ny);
-                    cx = second ? s.ax + nx : nx;
-                    cy = second ? s.ay + ny : ny;
-                } else if (b1) {
-                    cx = nx; cy = ny;
-                } else if (b2) {
-                    cx = s.ax + nx; cy = s.ay + ny;
+        // Short edges (nearly all edges where the image is densely covered): the candidates come pre-sorted from the
+        // table, the first occupied one IS the apex.  Four entries per table read, four independent bitmap probes.
+        if (g.tab != nullptr && s.ax >= -SDT_AMAX && s.ax <= SDT_AMAX && s.ay >= -SDT_AMAX && s.ay <= SDT_AMAX) {
+            const uint32_t* row = (const uint32_t*)(g.tab + sdt_index(s.ax, s.ay) * (SDT_LEN * 2));
+            for (int k = 0; k < SDT_LEN / 4; k++) {
+                const uint32_t e0 = row[2 * k], e1 = row[2 * k + 1];
+                const int x0 = (int8_t)(e0 & 0xFF), y0 = (int8_t)((e0 >> 8) & 0xFF), x1 = (int8_t)((e0 >> 16) & 0xFF), y1 = (int8_t)(e0 >> 24);
+                const int x2 = (int8_t)(e1 & 0xFF), y2 = (int8_t)((e1 >> 8) & 0xFF), x3 = (int8_t)((e1 >> 16) & 0xFF), y3 = (int8_t)(e1 >> 24);
+                const bool b0 = sdl_bit(g, s.sx + x0, s.sy + y0), b1 = sdl_bit(g, s.sx + x1, s.sy + y1);
+                const bool b2 = sdl_bit(g, s.sx + x2, s.sy + y2), b3 = sdl_bit(g, s.sx + x3, s.sy + y3);
+                if (b0 | b1 | b2 | b3) {
+                    s.px = b0 ? x0 : b1 ? x1 : b2 ? x2 : x3;
+                    s.py = b0 ? y0 : b1 ? y1 : b2 ? y2 : y3;
+                    s.cert = true;
+                    s.stage = 1;
+                    s.upDone = s.dnDone = true;  // the next iteration goes straight to the end-of-query logic
+                    break;
                 }
-            } else {
-                const int qx = (s.ax + nx) / 2, qy = (s.ay + ny) / 2;  // exact: both sums are even
-                if (sdl_bit(g, s.sx + qx, s.sy + qy)) { cx = qx; cy = qy; }
-            }
-            if (cx != SDL_NONE) {
-                sdl_set_apex(s, cx, cy);
-                s.stage = 1;
-                s.upDone = s.dnDone = true;  // the next iteration goes straight to the end-of-query logic
             }
         }
     } else {
@@ -246,7 +242,7 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
                 sdl_start_query(s, g, SDL_MODE_APEX);
                 return SDL_CONTINUE;
             }
-            if (s.stage == 0) {
+            if (s.stage == 0 && !s.cert) {
                 // the stage-0 sweep saw every site of the search disc; is that all of the candidate's circle?
                 bool enough = false;
                 if (have) {
@@ -261,10 +257,12 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
                 }
             }
             if (!have) return SDL_SITE_HARD;  // nothing in the window (hull edge, or a far apex)
-            const float rr = SDL_SQRT(s.r2) * 1.000001f + 0.26f;
-            if (s.ux - rr < (float)SDL_XLO || s.ux + rr > (float)SDL_XHI || s.uy - rr < (float)-SDL_HALF ||
-                s.uy + rr > (float)SDL_HALF)
-                return SDL_SITE_HARD;  // the circle leaves the window: not certified
+            if (!s.cert) {
+                const float rr = SDL_SQRT(s.r2) * 1.000001f + 0.26f;
+                if (s.ux - rr < (float)SDL_XLO || s.ux + rr > (float)SDL_XHI || s.uy - rr < (float)-SDL_HALF ||
+                    s.uy + rr > (float)SDL_HALF)
+                    return SDL_SITE_HARD;  // the circle leaves the window: not certified
+            }
             // triangle (s, a, p); s owns it iff it is the raster-first vertex
             if (sd_before(0, 0, s.ax, s.ay) && sd_before(0, 0, s.px, s.py))
                 emit(s.sx, s.sy, s.sx + s.ax, s.sy + s.ay, s.sx + s.px, s.sy + s.py);

@@ -3,6 +3,16 @@
 #include <vector>
 #include <cstring>
 #include "../../salve_amd/csrc/star_delaunay.h"
+#include "../../salve_amd/csrc/star_table.h"
+
+static const int8_t* host_table() {
+    static SdTable t;
+    static bool ok = sdt_build(&t);
+    return ok ? &t.off[0][0][0] : nullptr;
+}
+extern "C" int star_host_table_ok() { return host_table() != nullptr; }
+static int g_use_table = 1;
+extern "C" void star_host_use_table(int on) { g_use_table = on; }
 
 struct Collect {
     std::vector<int>* out;
@@ -14,6 +24,8 @@ struct Collect {
 
 extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H, int W, int* tri_xy, int cap,
                                      long long* total_steps) {
+    const bool use_table = g_use_table != 0;
+    if (use_table && !host_table()) return -3;
     int wpr = (W + 31) / 32;
     std::vector<uint32_t> occ((size_t)H * wpr, 0);
     std::vector<int16_t> rmin(H, (int16_t)W), rmax(H, (int16_t)-1);
@@ -22,7 +34,7 @@ extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H,
         if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
         if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
     }
-    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1};
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr};
     std::vector<int> out;
     Collect c = {&out};
     long long steps = 0;
@@ -44,6 +56,8 @@ extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H,
 // [1] hard sites, [2] max iterations of one site.
 extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, int H, int W, int* tri_xy, int cap,
                                            long long* stats) {
+    const bool use_table = g_use_table != 0;
+    if (use_table && !host_table()) return -3;
     int wpr = (W + 31) / 32;
     std::vector<uint32_t> occ((size_t)H * wpr, 0);
     std::vector<int16_t> rmin(H, (int16_t)W), rmax(H, (int16_t)-1);
@@ -52,7 +66,7 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
         if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
         if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
     }
-    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1};
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr};
     std::vector<int> out;
     Collect c = {&out};
     long long iters = 0, hard = 0, maxit = 0;

@@ -40,8 +40,15 @@ def oracle_tris(pts):
     return sorted(map(tuple, np.sort(sp[tri][:, :, 1] * 4096 + sp[tri][:, :, 0], 1).tolist()))
 
 
+def test_candidate_table_is_certified(lib):
+    """star_table.h: the pre-sorted apex candidates of short edges were enumerated completely."""
+    assert lib.star_host_table_ok() == 1
+
+
+@pytest.mark.parametrize("table", [1, 0])
 @pytest.mark.parametrize("which", ["star_host_triangulate", "star_host_triangulate_local"])
-def test_random_lattice_sets(lib, which):
+def test_random_lattice_sets(lib, which, table):
+    lib.star_host_use_table(table)
     rng = np.random.default_rng(5)
     done = 0
     for _ in range(250):
@@ -67,8 +74,10 @@ def test_structured_degenerate_sets(lib):
     ring = np.unique(np.round(np.stack([30 + 25 * np.cos(th), 30 + 25 * np.sin(th)], 1)).astype(int), axis=0)
     for pts, G in ((full, 17), (line, 20), (ring, 61), (full[::2], 17)):
         ref = oracle_tris(pts)
-        for which in ("star_host_triangulate", "star_host_triangulate_local"):
-            assert run(getattr(lib, which), pts, G, G)[0] == ref
+        for table in (1, 0):
+            lib.star_host_use_table(table)
+            for which in ("star_host_triangulate", "star_host_triangulate_local"):
+                assert run(getattr(lib, which), pts, G, G)[0] == ref
 
 
 def test_realistic_render_sites(lib):
@@ -79,6 +88,9 @@ def test_realistic_render_sites(lib):
     res = bo.render_bev_image(a, mode="exact")
     sp, tri = res["site_xy_sorted"], res["tri"]
     ref = sorted(map(tuple, np.sort(sp[tri][:, :, 1] * 4096 + sp[tri][:, :, 0], 1).tolist()))
+    lib.star_host_use_table(0)
+    assert run(lib.star_host_triangulate_local, sp, 501, 501)[0] == ref
+    lib.star_host_use_table(1)
     got, stats = run(lib.star_host_triangulate_local, sp, 501, 501)
     assert got == ref
     assert stats[1] < 0.05 * len(sp)  # only a few per cent of the sites need the general walk
