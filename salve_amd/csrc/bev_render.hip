@@ -28,6 +28,11 @@
 enum { SDC_apex = 0, SDC_apex_slow, SDC_apex_far, SDC_rows, SDC_bits, SDC_exact, SDC_apex_table, SDC_N };
 __shared__ int sd_counters[SDC_N];
 #define SD_COUNT(c) atomicAdd(&sd_counters[SDC_##c], 1)
+// ... and where its time goes: wave-clock laps (units of 16 cycles), lane 0 of each wave
+enum { SDP_table = 0, SDP_window, SDP_share, SDP_slow, SDP_far, SDP_e2_total, SDP_e1_total, SDP_nearest, SDP_N };
+__shared__ int sd_timers[SDP_N];
+#define SD_NOW() clock64()
+#define SD_LAP(slot, t) { const long long now_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&sd_timers[SDP_##slot], (int)((now_ - (t)) >> 4)); (t) = now_; }
 #endif
 #include "star_delaunay.h"
 #include "star_local.h"
@@ -311,8 +316,9 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
 
 #if defined(SALVE_PROFILE_WALK)
     if (tid < SDC_N) sd_counters[tid] = 0;
+    if (tid < SDP_N) sd_timers[tid] = 0;
 #endif
-    if (tid < 12) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : 0);  // [6] site cursor [7] hard sites [8] queued triangles
+    if (tid < 16) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : (tid == 12 ? H : (tid == 13 ? -1 : 0)));  // [12] min y [13] max y  // [6] site cursor [7] hard sites [8] queued triangles
     __syncthreads();
 
     // ---- phase B: bitmaps by wave ballot (no LDS atomics), row extents, compact site list.
@@ -366,6 +372,8 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
             if (hi >= 0) {
                 atomicMin(&scal[1], lo);
                 atomicMax(&scal[2], hi);
+                atomicMin(&scal[12], y);
+                atomicMax(&scal[13], y);
                 atomicAdd(&scal[3], 1);
             }
         }
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     //      E2: hard sites (hull, sparse regions: a few %) walk their star with the general algorithm and rasterise
     //          in place.   F: all lanes rasterise the queued triangles.
     if (!degenerate && !(c.dbg_flags & 1)) {
-        SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0]};
+        SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13]};
         RasterEmit raster = {H, W, wpr, occ, msk, keys, bev, (c.out_flags & 1) ? -1 : H - 1, 0, 1, (c.dbg_flags & 2) != 0};
         QueueEmit qemit = {triq, &scal[8], H * W, raster};
         SdLocal st;
@@ -476,6 +484,9 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
         const int nhard = scal[7];
         const int nq = min(scal[8], H * W);
         int err = 0;
+#if defined(SALVE_PROFILE_WALK)
+        long long t_e2 = SD_NOW();
+#endif
         {   // E2: one wavefront per hard site; its row sweeps and its rasterisation are shared by the 64 lanes
             SdGrid gw = g;
             gw.lane = lane;
@@ -488,6 +499,9 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
                 if (sd_star(gw, (int)(s & 0xFFFFu), (int)(s >> 16), rw) < 0) err = 1;
             }
         }
+#if defined(SALVE_PROFILE_WALK)
+        SD_LAP(e2_total, t_e2);
+#endif
         if (err) atomicOr(&scal[5], 1);
         for (int i = tid; i < ((c.dbg_flags & 8) ? 0 : nq); i += DENSIFY_THREADS) {
             const unsigned long long e = __hip_atomic_load(triq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
     if (dbg_stats) {
         __syncthreads();
 #if defined(SALVE_PROFILE_WALK)
-        if (tid < 8) dbg_stats[rid * 8 + tid] = tid < 6 ? sd_counters[tid] : scal[tid + 1];
+        if (tid < 8) dbg_stats[rid * 8 + tid] = (c.dbg_flags & 64) ? sd_timers[tid] : (tid < 7 ? sd_counters[tid] : scal[7]);
 #else
         if (tid < 8) dbg_stats[rid * 8 + tid] = tid == 1 ? scal[9] : (tid == 2 ? scal[10] : (tid < 6 ? scal[tid] : scal[tid + 1]));  // [1] sites begun [2] checksum [6] hard sites [7] queued triangles
 #endif

@@ -35,6 +35,7 @@ struct SdGrid {
     // rows lane, lane + nlanes, ... of every sweep and the lanes merge their candidates (sd_share_best).
     int lane, nlanes;     // 0, 1 for a caller that sweeps alone
     const int8_t* tab;    // SdTable (star_table.h) or nullptr: apex candidates of short edges, best first
+    int bx0, bx1, by0, by1;  // bounding box of all sites (inclusive)
 };
 
 // Table of apex candidates for short edges (built by star_table.h): for the edge vector (ax, ay) from the origin, the
@@ -58,6 +59,14 @@ SD_FN bool sd_occupied(const SdGrid& g, int x, int y) {
 
 SD_FN int32_t sd_orient(int ax, int ay, int bx, int by, int cx, int cy) {
     return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
+}
+
+// True if no site can lie strictly on side dir of s->a because the bounding box of all sites does not reach there:
+// then s->a is a hull edge.  Settles, without a sweep, the edges along the border of a cloud that was clipped to the
+// image window (most hull edges).
+SD_FN bool sd_side_is_empty(const SdGrid& g, int sx, int sy, int ax, int ay, int dir) {
+    return sd_orient(sx, sy, ax, ay, g.bx0, g.by0) * dir <= 0 && sd_orient(sx, sy, ax, ay, g.bx1, g.by0) * dir <= 0 &&
+           sd_orient(sx, sy, ax, ay, g.bx0, g.by1) * dir <= 0 && sd_orient(sx, sy, ax, ay, g.bx1, g.by1) * dir <= 0;
 }
 
 SD_FN bool sd_before(int ax, int ay, int bx, int by) { return ay < by || (ay == by && ax < bx); }
@@ -157,6 +166,10 @@ SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
 
 #ifndef SD_COUNT
 #define SD_COUNT(counter)
+#endif
+#ifndef SD_NOW
+#define SD_NOW() 0
+#define SD_LAP(slot, t) (void)(t)
 #endif
 
 // Scan rows ya, ya+step, ..., yb (step = +1 or -1), columns [xa, xb], for a better apex of the directed edge
@@ -299,6 +312,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     SdCircle circ = {0, 0, 0, 0};
     const SdEdge edge = sd_edge(sx, sy, ax, ay, dir);
     SD_COUNT(apex);
+    long long lap = SD_NOW();
     // 0. short edge: the pre-sorted candidate table answers with bitmap probes alone.  (Side -1 of s->a is side +1 of
     //    a->s, so the table is entered with the edge reversed.)
     if (g.tab != nullptr) {
@@ -319,6 +333,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
                 for (int k = 0; k < SDT_LEN && hit < 0; k++)
                     if (sd_occupied(g, ox + row[2 * k], oy + row[2 * k + 1])) hit = k;
             }
+            SD_LAP(table, lap);
             if (hit >= 0) {
                 SD_COUNT(apex_table);
                 *outx = ox + row[2 * hit];
@@ -327,16 +342,31 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
             }
         }
     }
-    // 1. a small window around the edge finds the apex in dense regions
-    const int M = SD_WINDOW_MARGIN;
-    int wy0 = (sy < ay ? sy : ay) - M, wy1 = (sy > ay ? sy : ay) + M;
-    int wx0 = (sx < ax ? sx : ax) - M, wx1 = (sx > ax ? sx : ax) + M;
-    if (wy0 < 0) wy0 = 0;
-    if (wx0 < 0) wx0 = 0;
-    if (wy1 > g.H - 1) wy1 = g.H - 1;
-    if (wx1 > g.W - 1) wx1 = g.W - 1;
-    sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0, wy1, 1, wx0, wx1, &px, &py, &circ);
-    sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
+    if (sd_side_is_empty(g, sx, sy, ax, ay, dir)) return false;
+    // 1. a small window around the edge finds the apex in dense regions; while it finds nothing it is widened
+    //    threefold (clipped to the bounding box of the sites).  Searching outwards keeps the first candidates few:
+    //    the previous, smaller window was empty, and every candidate found shrinks the circle for the others.
+    //    A window that covers the whole bounding box and is still empty proves s->a a hull edge.
+    int M = SD_WINDOW_MARGIN;
+    int wy0, wy1, wx0, wx1;
+    for (;;) {
+        wy0 = (sy < ay ? sy : ay) - M; wy1 = (sy > ay ? sy : ay) + M;
+        wx0 = (sx < ax ? sx : ax) - M; wx1 = (sx > ax ? sx : ax) + M;
+        if (wy0 < g.by0) wy0 = g.by0;
+        if (wx0 < g.bx0) wx0 = g.bx0;
+        if (wy1 > g.by1) wy1 = g.by1;
+        if (wx1 > g.bx1) wx1 = g.bx1;
+        sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0, wy1, 1, wx0, wx1, &px, &py, &circ);
+        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
+        if (px >= 0) break;
+        if (wy0 <= g.by0 && wx0 <= g.bx0 && wy1 >= g.by1 && wx1 >= g.bx1) {
+            SD_LAP(far, lap);
+            return false;
+        }
+        SD_COUNT(apex_far);
+        M = 3 * M + 2;
+    }
+    SD_LAP(window, lap);
     if (px >= 0) {
         // 2. whatever part of the candidate's circle sticks out of the window (and is on the image) is swept too
         const double r = circ.rpad;
@@ -353,17 +383,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
             if (cx1 > wx1) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, ry0, ry1, 1, wx1 + 1, cx1, &px, &py, &circ);
             sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
         }
-    } else {
-        // 3. nothing near the edge: the window's rows outside its columns, then away from the window downwards
-        //    and upwards.  An empty result means s->a is a hull edge.
-        SD_COUNT(apex_far);
-        if (wx0 > 0) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0, wy1, 1, 0, wx0 - 1, &px, &py, &circ);
-        if (wx1 < g.W - 1) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0, wy1, 1, wx1 + 1, g.W - 1, &px, &py, &circ);
-        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
-        if (wy1 < g.H - 1) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy1 + 1, g.H - 1, 1, 0, g.W - 1, &px, &py, &circ);
-        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
-        if (wy0 > 0) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0 - 1, 0, -1, 0, g.W - 1, &px, &py, &circ);
-        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
+        SD_LAP(slow, lap);
     }
     *outx = px;
     *outy = py;

@@ -32,6 +32,9 @@
 #define SDL_XHI 15
 #define SDL_NONE 0x7FFF
 
+#ifndef SDL_HARD
+#define SDL_HARD(reason) SDL_SITE_HARD   // a host build may count the reasons
+#endif
 enum { SDL_CONTINUE = 0, SDL_SITE_DONE = 1, SDL_SITE_HARD = 2 };
 enum { SDL_MODE_NEAREST = 0, SDL_MODE_APEX = 1 };
 
@@ -45,6 +48,7 @@ struct SdLocal {
     float hx, hy, hr2, inv_ay;  // stage 0 looks only inside this disc around the edge; a second sweep follows if that was not enough
     uint32_t bits;
     bool upDone, dnDone;
+    int dir;    // +1: walking counter-clockwise (apex left of s -> a); -1: clockwise, after the hull was met (table queries only)
     bool cert;  // the apex came from the table (star_table.h): exact and complete by construction, no circle test needed
     bool half;  // the walk started at the neighbour (+1, 0): stop at the first neighbour that precedes s in raster order
 };
@@ -96,22 +100,33 @@ SD_FN void sdl_start_query(SdLocal& s, const SdGrid& g, int mode) {
         // Short edges (nearly all edges where the image is densely covered): the candidates come pre-sorted from the
         // table, the first occupied one IS the apex.  Four entries per table read, four independent bitmap probes.
         if (g.tab != nullptr && s.ax >= -SDT_AMAX && s.ax <= SDT_AMAX && s.ay >= -SDT_AMAX && s.ay <= SDT_AMAX) {
-            const uint32_t* row = (const uint32_t*)(g.tab + sdt_index(s.ax, s.ay) * (SDT_LEN * 2));
+            // the right of s -> a is the left of a -> s: clockwise queries enter the table with the edge reversed
+            const int ox = s.dir > 0 ? 0 : s.ax, oy = s.dir > 0 ? 0 : s.ay;
+            const int vx = s.dir > 0 ? s.ax : -s.ax, vy = s.dir > 0 ? s.ay : -s.ay;
+            const uint32_t* row = (const uint32_t*)(g.tab + sdt_index(vx, vy) * (SDT_LEN * 2));
+            const int bx = s.sx + ox, by = s.sy + oy;
             for (int k = 0; k < SDT_LEN / 4; k++) {
                 const uint32_t e0 = row[2 * k], e1 = row[2 * k + 1];
                 const int x0 = (int8_t)(e0 & 0xFF), y0 = (int8_t)((e0 >> 8) & 0xFF), x1 = (int8_t)((e0 >> 16) & 0xFF), y1 = (int8_t)(e0 >> 24);
                 const int x2 = (int8_t)(e1 & 0xFF), y2 = (int8_t)((e1 >> 8) & 0xFF), x3 = (int8_t)((e1 >> 16) & 0xFF), y3 = (int8_t)(e1 >> 24);
-                const bool b0 = sdl_bit(g, s.sx + x0, s.sy + y0), b1 = sdl_bit(g, s.sx + x1, s.sy + y1);
-                const bool b2 = sdl_bit(g, s.sx + x2, s.sy + y2), b3 = sdl_bit(g, s.sx + x3, s.sy + y3);
+                const bool b0 = sdl_bit(g, bx + x0, by + y0), b1 = sdl_bit(g, bx + x1, by + y1);
+                const bool b2 = sdl_bit(g, bx + x2, by + y2), b3 = sdl_bit(g, bx + x3, by + y3);
                 if (b0 | b1 | b2 | b3) {
-                    s.px = b0 ? x0 : b1 ? x1 : b2 ? x2 : x3;
-                    s.py = b0 ? y0 : b1 ? y1 : b2 ? y2 : y3;
+                    s.px = ox + (b0 ? x0 : b1 ? x1 : b2 ? x2 : x3);
+                    s.py = oy + (b0 ? y0 : b1 ? y1 : b2 ? y2 : y3);
                     s.cert = true;
                     s.stage = 1;
                     s.upDone = s.dnDone = true;  // the next iteration goes straight to the end-of-query logic
                     break;
                 }
             }
+        }
+        if (!s.cert && sd_side_is_empty(g, s.sx, s.sy, s.sx + s.ax, s.sy + s.ay, s.dir)) {
+            s.stage = 2;                     // hull edge, certified by the bounding box of the sites
+            s.upDone = s.dnDone = true;
+        } else if (!s.cert && s.dir < 0) {
+            s.stage = 3;                     // clockwise queries have no sweep: the site goes to the general walk
+            s.upDone = s.dnDone = true;
         }
     } else {
         s.m = 0;
@@ -126,6 +141,7 @@ SD_FN void sdl_begin(SdLocal& s, const SdGrid& g, int sx, int sy) {
     s.sx = sx;
     s.sy = sy;
     s.deg = 0;
+    s.dir = 1;
     s.ax = s.ay = 0;
     // an 8-neighbour, if there is one, is a nearest site (distance 1 before sqrt 2) and needs no search
     const uint32_t c = sdl_row32(g, sy, sx + SDL_XLO), u = sdl_row32(g, sy + 1, sx + SDL_XLO), d = sdl_row32(g, sy - 1, sx + SDL_XLO);
@@ -236,9 +252,20 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
         } else if (s.upDone && s.dnDone) {
             // ---- sweep finished
             if (s.mode == SDL_MODE_NEAREST) {
-                if (!have || s.r2 > (float)(SDL_HALF * SDL_HALF)) return SDL_SITE_HARD;  // a site outside the window could be nearer
+                if (!have || s.r2 > (float)(SDL_HALF * SDL_HALF)) return SDL_HARD(0);  // a site outside the window could be nearer
                 s.n0x = s.ax = s.px;
                 s.n0y = s.ay = s.py;
+                sdl_start_query(s, g, SDL_MODE_APEX);
+                return SDL_CONTINUE;
+            }
+            if (s.stage == 3) return SDL_HARD(1);
+            if (s.stage == 2) {
+                // hull edge.  A half walk owns nothing beyond it; a full walk goes back to its first neighbour and
+                // fans out clockwise until it meets the hull on the other side.
+                if (s.half || s.dir < 0) return SDL_SITE_DONE;
+                s.dir = -1;
+                s.ax = s.n0x;
+                s.ay = s.n0y;
                 sdl_start_query(s, g, SDL_MODE_APEX);
                 return SDL_CONTINUE;
             }
@@ -256,19 +283,21 @@ SD_FN int sdl_iter(SdLocal& s, const SdGrid& g, Emit& emit) {
                     return SDL_CONTINUE;
                 }
             }
-            if (!have) return SDL_SITE_HARD;  // nothing in the window (hull edge, or a far apex)
+            if (!have) return SDL_HARD(2);  // nothing in the window (an interior hull edge, or a far apex)
             if (!s.cert) {
                 const float rr = SDL_SQRT(s.r2) * 1.000001f + 0.26f;
                 if (s.ux - rr < (float)SDL_XLO || s.ux + rr > (float)SDL_XHI || s.uy - rr < (float)-SDL_HALF ||
                     s.uy + rr > (float)SDL_HALF)
-                    return SDL_SITE_HARD;  // the circle leaves the window: not certified
+                    return SDL_HARD(3);  // the circle leaves the window: not certified
             }
-            // triangle (s, a, p); s owns it iff it is the raster-first vertex
-            if (sd_before(0, 0, s.ax, s.ay) && sd_before(0, 0, s.px, s.py))
-                emit(s.sx, s.sy, s.sx + s.ax, s.sy + s.ay, s.sx + s.px, s.sy + s.py);
-            if (s.px == s.n0x && s.py == s.n0y) return SDL_SITE_DONE;
+            // triangle (s, a, p) -- (s, p, a) when walking clockwise; s owns it iff it is the raster-first vertex
+            if (sd_before(0, 0, s.ax, s.ay) && sd_before(0, 0, s.px, s.py)) {
+                if (s.dir > 0) emit(s.sx, s.sy, s.sx + s.ax, s.sy + s.ay, s.sx + s.px, s.sy + s.py);
+                else emit(s.sx, s.sy, s.sx + s.px, s.sy + s.py, s.sx + s.ax, s.sy + s.ay);
+            }
+            if (s.dir > 0 && s.px == s.n0x && s.py == s.n0y) return SDL_SITE_DONE;
             if (s.half && !sd_before(0, 0, s.px, s.py)) return SDL_SITE_DONE;  // the rest of the star belongs to other sites
-            if (++s.deg > 64) return SDL_SITE_HARD;
+            if (++s.deg > 64) return SDL_HARD(4);
             s.ax = s.px;
             s.ay = s.py;
             sdl_start_query(s, g, SDL_MODE_APEX);

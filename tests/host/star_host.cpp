@@ -34,7 +34,14 @@ extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H,
         if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
         if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
     }
-    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr};
+    int bx0 = W, bx1 = -1, by0 = H, by1 = -1;
+    for (int i = 0; i < n; i++) {
+        if (xs[i] < bx0) bx0 = xs[i];
+        if (xs[i] > bx1) bx1 = xs[i];
+        if (ys[i] < by0) by0 = ys[i];
+        if (ys[i] > by1) by1 = ys[i];
+    }
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr, bx0, bx1, by0, by1};
     std::vector<int> out;
     Collect c = {&out};
     long long steps = 0;
@@ -50,7 +57,10 @@ extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H,
     return nt;
 }
 
+static long long g_hard_reason[8];
+#define SDL_HARD(reason) (g_hard_reason[reason]++, SDL_SITE_HARD)
 #include "../../salve_amd/csrc/star_local.h"
+extern "C" void star_host_hard_reasons(long long* out) { for (int i = 0; i < 8; i++) { out[i] = g_hard_reason[i]; g_hard_reason[i] = 0; } }
 
 // Local state machine for every site, general algorithm for the sites it hands over.  stats: [0] iterations,
 // [1] hard sites, [2] max iterations of one site.
@@ -66,7 +76,14 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
         if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
         if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
     }
-    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr};
+    int bx0 = W, bx1 = -1, by0 = H, by1 = -1;
+    for (int i = 0; i < n; i++) {
+        if (xs[i] < bx0) bx0 = xs[i];
+        if (xs[i] > bx1) bx1 = xs[i];
+        if (ys[i] < by0) by0 = ys[i];
+        if (ys[i] > by1) by1 = ys[i];
+    }
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr, bx0, bx1, by0, by1};
     std::vector<int> out;
     Collect c = {&out};
     long long iters = 0, hard = 0, maxit = 0;
