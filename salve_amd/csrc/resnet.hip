@@ -12,6 +12,7 @@
 // kernel: input channels are padded to 8 (or 16) and kw to 8 so that one k-tile is one kernel row.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -24,8 +25,7 @@ typedef __attribute__((__ext_vector_type__(8))) __bf16 bf16x8;
 typedef __attribute__((__ext_vector_type__(4))) float f32x4;
 
 constexpr int BM = 128;
-constexpr int BK = 64;
-constexpr int LDK = BK + 8;  // LDS row stride in elements (144 B): conflict-free 16-byte fragment reads
+constexpr int BK = 64;       // one k-tile = 64 bf16 = one 128-byte LDS row = 8 chunks of 16 bytes
 constexpr int CONV_THREADS = 256;
 
 struct ConvArgs {
@@ -34,8 +34,10 @@ struct ConvArgs {
     const float* bias;
     const uint16_t* res;
     uint16_t* out;
-    const int32_t* ktab;  // per 8-element chunk of K: dy | dx << 8 | channel offset << 16
+    const int32_t* ktab;    // per 8-element chunk of K: dy | dx << 8 | channel offset << 16
+    const uint16_t* zeros;  // >= 16 zero bytes: the source of padding taps and of rows beyond M
     int B, Hi, Wi, Cin, Ho, Wo, Cout, stride, pad, K, M, relu;
+    int m_tiles, n_tiles;
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
@@ -46,38 +48,56 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 
+typedef __attribute__((address_space(1))) const void* global_cptr;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// Staging: `global_load_lds_dwordx4` -- each lane names its own 16 source bytes (the im2col gather), the wave's 1 KiB
+// lands lane-linearly in LDS without passing through VGPRs or the ds_write path.  One wave-instruction fills 8 tile
+// rows of 128 bytes, so the LDS image is unpadded; bank conflicts of the 16-byte fragment reads are avoided by a swizzle
+// applied on the SOURCE side: LDS slot (row r, 16-byte slot q) holds k-chunk q ^ ((r >> 1) & 7).
+// One LDS stage (load, barrier, multiply, barrier; <= 35 KB): four workgroups per CU hide each other's latency.  Measured
+// on every layer of ResNet-50 at batch 512, that beats two stages with the next tile's loads in flight under the MFMAs
+// (64 KB, two workgroups per CU) by 25-45 %: occupancy, not explicit pipelining, is what this tile size wants.
 template <int BN>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p) {
     constexpr int WN = BN / 2;       // wave tile width
     constexpr int NT = WN / 16;      // 16-wide MFMA tiles per wave along n
     constexpr int B_LOADS = BN / 32; // 16-byte chunks of the weight tile per thread
     constexpr int LDC = BN + 8;
-    constexpr int AB_ELEMS = (BM + BN) * LDK;
+    constexpr int STAGE_ELEMS = (BM + BN) * BK;
     constexpr int C_ELEMS = BM * LDC;
-    __shared__ __attribute__((aligned(16))) uint16_t smem[AB_ELEMS > C_ELEMS ? AB_ELEMS : C_ELEMS];
-    uint16_t* As = smem;
-    uint16_t* Bs = smem + BM * LDK;
+    __shared__ __attribute__((aligned(1024))) uint16_t smem[STAGE_ELEMS > C_ELEMS ? STAGE_ELEMS : C_ELEMS];
 
+    // Workgroup -> tile, XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so
+    // the n-tiles of one m-tile (same activation rows) are given ids that share id % 8 and run close together in time.
+    int m_tile, n_tile;
+    {
+        const int per_group = 8 * p.n_tiles;
+        const int g = blockIdx.x / per_group, r = blockIdx.x % per_group;
+        m_tile = g * 8 + (r & 7);
+        n_tile = r >> 3;
+        if (m_tile >= p.m_tiles) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int chunk = tid & 7;  // which 16-byte chunk of the 64-wide k-tile this thread stages
-    const int row_base = tid >> 3;  // 0..31, plus i * 32
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int row_base = tid >> 3;                           // 0..31, plus i * 32
+    const int chunk = (tid & 7) ^ ((row_base >> 1) & 7);     // the k-chunk this thread fetches (source-side swizzle)
 
     // per-thread im2col rows (fixed for the whole K loop)
     int iy0[4], ix0[4];
     long long boff[4];
-    bool rvalid[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int m = m0 + row_base + i * 32;
-        rvalid[i] = m < p.M;
-        const int mm = rvalid[i] ? m : 0;
+        const bool valid = m < p.M;
+        const int mm = valid ? m : 0;
         const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-        iy0[i] = oy * p.stride - p.pad;
+        iy0[i] = valid ? oy * p.stride - p.pad : -100000;  // rows beyond M read zeros
         ix0[i] = ox * p.stride - p.pad;
         boff[i] = (long long)b * p.Hi * p.Wi;
     }
+    const uint16_t* wrow = p.w + (long long)(n0 + row_base) * p.K + chunk * 8;
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -85,62 +105,46 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
 #pragma unroll
         for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4];
-    uint4 rb0 = uint4{0u, 0u, 0u, 0u}, rb1 = rb0, rb2 = rb0, rb3 = rb0;  // named, not an array: hipcc kept rb[] in scratch
     const int nkt = p.K / BK;
 
-    // staging as macros (lambdas capturing the register arrays by reference made hipcc keep them in scratch)
-#define LOAD_TILE(KT)                                                                                                  \
+#define ISSUE_TILE(KT, STAGE, E)                                                                                       \
     {                                                                                                                  \
-        const int32_t e_ = p.ktab[(KT) * 8 + chunk];                                                                   \
-        const int dy_ = (int8_t)(e_ & 0xFF), dx_ = (int8_t)((e_ >> 8) & 0xFF), coff_ = (e_ >> 16) & 0xFFFF;            \
+        uint16_t* As_ = smem + (STAGE) * STAGE_ELEMS + wave * 8 * BK;                                                  \
+        uint16_t* Bs_ = As_ + BM * BK;                                                                                 \
+        const int dy_ = (int8_t)((E) & 0xFF), dx_ = (int8_t)(((E) >> 8) & 0xFF), coff_ = ((E) >> 16) & 0xFFFF;          \
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                \
             const int iy = iy0[i] + dy_, ix = ix0[i] + dx_;                                                            \
-            const bool ok = rvalid[i] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;                                 \
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(p.in + ((boff[i] + (long long)iy * p.Wi + ix) * p.Cin + coff_)) \
-                       : uint4{0u, 0u, 0u, 0u};                                                                        \
+            const bool ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;                                              \
+            const uint16_t* src = ok ? p.in + ((boff[i] + (long long)iy * p.Wi + ix) * p.Cin + coff_) : p.zeros;       \
+            __builtin_amdgcn_global_load_lds((global_cptr)src, (lds_ptr)(As_ + i * 32 * BK), 16, 0, 0);                \
         }                                                                                                              \
-        {                                                                                                              \
-            const uint16_t* wp_ = p.w + (long long)(n0 + row_base) * p.K + (KT) * BK + chunk * 8;                      \
-            rb0 = *reinterpret_cast<const uint4*>(wp_);                                                                \
-            rb1 = *reinterpret_cast<const uint4*>(wp_ + 32ll * p.K);                                                   \
-            if (B_LOADS > 2) {                                                                                         \
-                rb2 = *reinterpret_cast<const uint4*>(wp_ + 64ll * p.K);                                               \
-                rb3 = *reinterpret_cast<const uint4*>(wp_ + 96ll * p.K);                                               \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-#define STORE_TILE()                                                                                                   \
-    {                                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; i++)                                                                  \
-            *reinterpret_cast<uint4*>(As + (row_base + i * 32) * LDK + chunk * 8) = ra[i];                             \
-        *reinterpret_cast<uint4*>(Bs + (row_base)*LDK + chunk * 8) = rb0;                                              \
-        *reinterpret_cast<uint4*>(Bs + (row_base + 32) * LDK + chunk * 8) = rb1;                                       \
-        if (B_LOADS > 2) {                                                                                             \
-            *reinterpret_cast<uint4*>(Bs + (row_base + 64) * LDK + chunk * 8) = rb2;                                   \
-            *reinterpret_cast<uint4*>(Bs + (row_base + 96) * LDK + chunk * 8) = rb3;                                   \
-        }                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < B_LOADS; j++)                                                            \
+            __builtin_amdgcn_global_load_lds((global_cptr)(wrow + (long long)j * 32 * p.K + (KT) * BK),                \
+                                             (lds_ptr)(Bs_ + j * 32 * BK), 16, 0, 0);                                  \
     }
 
-    LOAD_TILE(0);
+    int32_t e_next = p.ktab[chunk];
+    const int frag_row = lane & 15, frag_q = lane >> 4, frag_sw = (frag_row >> 1) & 7;
     for (int kt = 0; kt < nkt; kt++) {
-        __syncthreads();  // previous tile's fragment reads are done
-        STORE_TILE();
-        __syncthreads();
-        {   // next tile in flight under the MFMAs below (the last iteration re-loads its own tile: branch-free, so the
-            // staging registers never go through scratch)
-            const int kn = kt + 1 < nkt ? kt + 1 : kt;
-            LOAD_TILE(kn);
+        ISSUE_TILE(kt, 0, e_next);
+        {   // table entry of the next tile: a plain load, first used in the next iteration
+            const int k1 = kt + 1 < nkt ? kt + 1 : nkt - 1;
+            e_next = p.ktab[k1 * 8 + chunk];
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the tile has landed
+        __syncthreads();                                  // ... everyone's
+        const uint16_t* As = smem;
+        const uint16_t* Bs = As + BM * BK;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ks++) {
             bf16x8 af[4], bfr[NT];
+            const int slot = ((ks * 4 + frag_q) ^ frag_sw) * 8;
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                af[i] = *reinterpret_cast<const bf16x8*>(As + (wr * 64 + i * 16 + (lane & 15)) * LDK + ks * 32 + (lane >> 4) * 8);
+                af[i] = *reinterpret_cast<const bf16x8*>(As + (wr * 64 + i * 16 + frag_row) * BK + slot);
 #pragma unroll
             for (int j = 0; j < NT; j++)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + (wc * WN + j * 16 + (lane & 15)) * LDK + ks * 32 + (lane >> 4) * 8);
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + (wc * WN + j * 16 + frag_row) * BK + slot);
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -149,13 +153,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
                     // channels of one output pixel (8 bytes of the NHWC row) instead of 4 pixels of one channel
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();  // everyone is done reading the tile
     }
+#undef ISSUE_TILE
 
-#undef LOAD_TILE
-#undef STORE_TILE
     // ---- epilogue: (residual tile ->) LDS, add bias / residual / ReLU in fp32 on the accumulator's own elements,
     //      round once to bf16, then 16-byte coalesced stores.
-    __syncthreads();
     uint16_t* Cs = smem;
     constexpr int CH_PER_ROW = BN / 8;
     constexpr int C_ITERS = (BM * CH_PER_ROW) / CONV_THREADS;
@@ -244,33 +247,46 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict
     *reinterpret_cast<uint4*>(out + (((long long)b * Ho + oy) * Wo + ox) * C + ch * 8) = uint4{o[0], o[1], o[2], o[3]};
 }
 
-// Global average pool over HW positions + fully connected layer (fp32 weights), one block per sample.
+// Global average pool over HW positions + fully connected layer (fp32 weights), one block per sample.  A thread owns 8
+// consecutive channels (16-byte loads, coalesced across the block) and walks the positions; the per-class partial dot
+// products are then reduced across the block.
 __global__ __launch_bounds__(256) void avgpool_fc_kernel(const uint16_t* __restrict__ in, int HW, int C,
                                                          const float* __restrict__ fcw, const float* __restrict__ fcb,
                                                          int ncls, float* __restrict__ logits) {
-    extern __shared__ float red[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[8][4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint16_t* x = in + (long long)b * HW * C;
     float part[8];  // ncls <= 8
 #pragma unroll
     for (int k = 0; k < 8; k++) part[k] = 0.f;
     const float inv = 1.0f / (float)HW;
-    for (int c = tid; c < C; c += 256) {
-        float s = 0.f;
-        for (int i = 0; i < HW; i++) s += bf16_to_f32(x[(long long)i * C + c]);
-        s *= inv;
-        for (int k = 0; k < ncls; k++) part[k] += s * fcw[(long long)k * C + c];
-    }
-    for (int k = 0; k < ncls; k++) {
-        red[tid] = part[k];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) red[tid] += red[tid + s];
-            __syncthreads();
+    for (int c0 = tid * 8; c0 < C; c0 += 256 * 8) {
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) s[e] = 0.f;
+        for (int i = 0; i < HW; i++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + (long long)i * C + c0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                s[2 * e] += bf16_to_f32((uint16_t)(w[e] & 0xFFFFu));
+                s[2 * e + 1] += bf16_to_f32((uint16_t)(w[e] >> 16));
+            }
         }
-        if (tid == 0) logits[(long long)b * ncls + k] = red[0] + fcb[k];
-        __syncthreads();
+        for (int k = 0; k < ncls; k++) {
+            const float* wk = fcw + (long long)k * C + c0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) part[k] += (s[e] * inv) * wk[e];
+        }
     }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        float v = part[k];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (tid < ncls) logits[(long long)b * ncls + tid] = ((red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3])) + fcb[tid];
 }
 
 struct ResnetHandle {
@@ -278,6 +294,7 @@ struct ResnetHandle {
     uint16_t* d_weights = nullptr;
     float* d_params = nullptr;
     int32_t* d_ktab = nullptr;
+    uint16_t* d_zeros = nullptr;
     size_t max_act_elems = 0;  // per sample, elements of the largest activation buffer
     int n_bufs = 0;
     int num_layers = 0, in_channels = 0, ncls = 0;
@@ -292,6 +309,7 @@ bool check_op(const salve_resnet_op_t& o) {
         if (o.Cin % 8 != 0) return salve_fail("maxpool: C must be a multiple of 8");
     } else if (o.op == SALVE_OP_AVGPOOL_FC) {
         if (o.Cout < 1 || o.Cout > 8) return salve_fail("fc: 1..8 classes supported");
+        if (o.Cin % 8 != 0) return salve_fail("fc: C must be a multiple of 8");
     } else {
         return salve_fail("unknown op");
     }
@@ -325,14 +343,15 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
         }
     }
     if (hipMalloc(&h->d_weights, weights_bytes) != hipSuccess || hipMalloc(&h->d_params, params_bytes) != hipSuccess ||
-        hipMalloc(&h->d_ktab, ktab_entries * sizeof(int32_t)) != hipSuccess) {
+        hipMalloc(&h->d_ktab, ktab_entries * sizeof(int32_t)) != hipSuccess || hipMalloc(&h->d_zeros, 256) != hipSuccess) {
         salve_fail("salve_resnet_create: hipMalloc failed");
         salve_resnet_destroy(h);
         return nullptr;
     }
     if (hipMemcpy(h->d_weights, weights_bf16, weights_bytes, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_params, params_f32, params_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->d_ktab, ktab, ktab_entries * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(h->d_ktab, ktab, ktab_entries * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(h->d_zeros, 0, 256) != hipSuccess) {
         salve_fail("salve_resnet_create: hipMemcpy failed");
         salve_resnet_destroy(h);
         return nullptr;
@@ -346,6 +365,7 @@ void salve_resnet_destroy(void* handle) {
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_ktab) (void)hipFree(h->d_ktab);
+    if (h->d_zeros) (void)hipFree(h->d_zeros);
     delete h;
 }
 
@@ -381,23 +401,27 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.res = o.res_buf != SALVE_NO_BUF ? buf(o.res_buf) : nullptr;
             a.out = buf(o.out_buf);
             a.ktab = h->d_ktab + o.ktab_off;
+            a.zeros = h->d_zeros;
             a.B = batch; a.Hi = o.Hi; a.Wi = o.Wi; a.Cin = o.Cin; a.Ho = o.Ho; a.Wo = o.Wo; a.Cout = o.Cout;
             a.stride = o.stride; a.pad = o.pad; a.K = o.KH * o.KW * o.Cin; a.relu = o.relu;
             const long long M = (long long)batch * o.Ho * o.Wo;
             if (M > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
             a.M = (int)M;
-            const int gm = (int)((M + BM - 1) / BM);
-            if (o.Cout % 128 == 0) {
-                hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(gm, o.Cout / 128), dim3(CONV_THREADS), 0, s, a);
+            a.m_tiles = (int)((M + BM - 1) / BM);
+            const int bn = (o.Cout % 128 == 0) ? 128 : 64;
+            a.n_tiles = o.Cout / bn;
+            const unsigned grid = (unsigned)(((a.m_tiles + 7) / 8) * 8 * a.n_tiles);
+            if (bn == 128) {
+                hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, s, a);
             } else {
-                hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(gm, o.Cout / 64), dim3(CONV_THREADS), 0, s, a);
+                hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, s, a);
             }
         } else if (o.op == SALVE_OP_MAXPOOL) {
             const long long total = (long long)batch * o.Ho * o.Wo * (o.Cin / 8);
             hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, buf(o.in_buf), buf(o.out_buf),
                                batch, o.Hi, o.Wi, o.Cin, o.Ho, o.Wo);
         } else {
-            hipLaunchKernelGGL(avgpool_fc_kernel, dim3(batch), dim3(256), 256 * sizeof(float), s, buf(o.in_buf), o.Hi * o.Wi,
+            hipLaunchKernelGGL(avgpool_fc_kernel, dim3(batch), dim3(256), 0, s, buf(o.in_buf), o.Hi * o.Wi,
                                o.Cin, h->d_params + o.w_off, h->d_params + o.b_off, o.Cout, logits);
         }
         SALVE_HIP_CHECK(hipGetLastError());
