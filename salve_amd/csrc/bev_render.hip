@@ -179,7 +179,8 @@ struct RasterEmit {
 
     __device__ __forceinline__ void operator()(int ax, int ay, int bx, int by, int cx, int cy) const {
         const int32_t area = sd_orient(ax, ay, bx, by, cx, cy);
-        if (area <= 0 || skip) return;
+        // area == 1 (twice the area): by Pick's theorem the triangle holds no lattice point besides its vertices
+        if (area <= 1 || skip) return;
         int x0 = min(ax, min(bx, cx)), x1 = max(ax, max(bx, cx));
         const int y0 = min(ay, min(by, cy)), y1 = max(ay, max(by, cy));
         uint32_t ca = 0, cb = 0, cc = 0;
@@ -247,6 +248,9 @@ struct QueueEmit {
     int capacity;
     RasterEmit fallback;
     __device__ __forceinline__ void operator()(int ax, int ay, int bx, int by, int cx, int cy) const {
+        // most triangles of a densely covered region are unit lattice triangles (twice the area = 1): no lattice point
+        // other than the vertices lies in them (Pick), nothing to interpolate
+        if (sd_orient(ax, ay, bx, by, cx, cy) <= 1) return;
         const int slot = atomicAdd(counter, 1);
         if (slot < capacity) {
             const uint32_t rel = (uint32_t)((bx - ax) & 0xFF) | ((uint32_t)((by - ay) & 0xFF) << 8) |
@@ -443,11 +447,11 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
         SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13]};
         RasterEmit raster = {H, W, wpr, occ, msk, keys, bev, (c.out_flags & 1) ? -1 : H - 1, 0, 1, (c.dbg_flags & 2) != 0};
         QueueEmit qemit = {triq, &scal[8], H * W, raster};
-        SdLocal st;
+        SdLean st;
         bool active = false, exhausted = false;
         int iters = 0;
         for (;;) {
-            // Idle lanes are refilled in batches: the (long) site set-up code is then issued once per ~16 finished sites
+            // Idle lanes are refilled in batches: the site set-up code is then issued once per ~16 finished sites
             // instead of in nearly every iteration, at the price of a few lane-iterations of idling.
             const unsigned long long idle = __ballot(!active && !exhausted);
             const unsigned long long busy = __ballot(active);
@@ -458,24 +462,24 @@ __global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
                         exhausted = true;
                     } else {
                         const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sdl_begin(st, g, (int)(s & 0xFFFFu), (int)(s >> 16));
-                        active = true;
                         if (dbg_stats) { atomicAdd(&scal[9], 1); atomicAdd(&scal[10], (int)(s & 0xFFFFu) + (int)(s >> 16)); }
+                        if (sdl_lean_begin(st, g, (int)(s & 0xFFFFu), (int)(s >> 16)) == SDL_LEAN_CONTINUE) active = true;
+                        else __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             } else if (busy == 0ull) {
                 break;  // every lane is exhausted and idle
             }
             if (active) {
-                const int r = sdl_iter(st, g, qemit);
+                const int r = sdl_lean_step(st, g, qemit);
                 iters++;
-                if (r != SDL_CONTINUE) {
+                if (r != SDL_LEAN_CONTINUE) {
                     active = false;
-                    if (dbg_mask && (c.dbg_flags & 16))  // development: how each site's local walk ended
+                    if (dbg_mask && (c.dbg_flags & 16))  // development: how each site's lean walk ended
                     {
-                        dbg_mask[((size_t)rid * H + st.sy) * W + st.sx] = (uint8_t)((r == SDL_SITE_HARD ? 200 : 100) + min(st.deg, 50));
+                        dbg_mask[((size_t)rid * H + st.sy) * W + st.sx] = (uint8_t)((r == SDL_LEAN_HARD ? 200 : 100) + min(st.deg, 50));
                     }
-                    if (r == SDL_SITE_HARD) __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (r == SDL_LEAN_HARD) __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }

@@ -57,13 +57,10 @@ extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H,
     return nt;
 }
 
-static long long g_hard_reason[8];
-#define SDL_HARD(reason) (g_hard_reason[reason]++, SDL_SITE_HARD)
 #include "../../salve_amd/csrc/star_local.h"
-extern "C" void star_host_hard_reasons(long long* out) { for (int i = 0; i < 8; i++) { out[i] = g_hard_reason[i]; g_hard_reason[i] = 0; } }
 
-// Local state machine for every site, general algorithm for the sites it hands over.  stats: [0] iterations,
-// [1] hard sites, [2] max iterations of one site.
+// Lean walk (star_local.h) for every site, general algorithm for the sites it hands over -- the kernel's two phases.
+// stats: [0] lean iterations, [1] hard sites, [2] max iterations of one site.
 extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, int H, int W, int* tri_xy, int cap,
                                            long long* stats) {
     const bool use_table = g_use_table != 0;
@@ -71,13 +68,11 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
     int wpr = (W + 31) / 32;
     std::vector<uint32_t> occ((size_t)H * wpr, 0);
     std::vector<int16_t> rmin(H, (int16_t)W), rmax(H, (int16_t)-1);
+    int bx0 = W, bx1 = -1, by0 = H, by1 = -1;
     for (int i = 0; i < n; i++) {
         occ[(size_t)ys[i] * wpr + (xs[i] >> 5)] |= 1u << (xs[i] & 31);
         if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
         if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
-    }
-    int bx0 = W, bx1 = -1, by0 = H, by1 = -1;
-    for (int i = 0; i < n; i++) {
         if (xs[i] < bx0) bx0 = xs[i];
         if (xs[i] > bx1) bx1 = xs[i];
         if (ys[i] < by0) by0 = ys[i];
@@ -88,19 +83,18 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
     Collect c = {&out};
     long long iters = 0, hard = 0, maxit = 0;
     for (int i = 0; i < n; i++) {
-        SdLocal st;
-        sdl_begin(st, g, xs[i], ys[i]);
         std::vector<int> mine;
         Collect cm = {&mine};
+        SdLean ls;
         long long it = 0;
-        int r;
-        do { r = sdl_iter(st, g, cm); it++; } while (r == SDL_CONTINUE && it < 100000);
+        int r = sdl_lean_begin(ls, g, xs[i], ys[i]);
+        while (r == SDL_LEAN_CONTINUE && it < 100000) { r = sdl_lean_step(ls, g, cm); it++; }
         iters += it;
         if (it > maxit) maxit = it;
-        if (r == SDL_SITE_DONE) {
+        if (r == SDL_LEAN_DONE) {
             out.insert(out.end(), mine.begin(), mine.end());
         } else {
-            hard++;
+            hard++;   // the kernel rasterises what the lean walk had emitted, and then the general walk's triangles again
             if (sd_star(g, xs[i], ys[i], c) < 0) return -1;
         }
     }
