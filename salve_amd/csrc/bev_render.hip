@@ -296,7 +296,7 @@ static int ensure_star_table() {
     return SALVE_OK;
 }
 
-__global__ __launch_bounds__(DENSIFY_THREADS) void bev_densify_kernel(
+__global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     DevCfg c, const unsigned long long* __restrict__ keys_all, uint32_t* __restrict__ bev_all,
     uint32_t* __restrict__ sitelist_all, uint32_t* __restrict__ hardlist_all, unsigned long long* __restrict__ triq_all,
     uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats, int16_t* __restrict__ dbg_aux) {

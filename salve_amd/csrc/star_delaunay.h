@@ -172,145 +172,190 @@ SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
 #define SD_LAP(slot, t) (void)(t)
 #endif
 
-// Scan rows ya, ya+step, ..., yb (step = +1 or -1), columns [xa, xb], for a better apex of the directed edge
-// s->a on side dir.  (px,py) < 0 means "none yet".  Rows are cut to their occupied extent; wide scans are also cut,
-// before the bitmap is touched, to the open half-plane on side dir of the line s->a and to the current candidate
-// circle (supersets with a safety margin), so rows on the wrong side cost a few instructions and the work shrinks
-// as the apex improves.  A sweep stops once it has left the circle in its direction of travel.  Every surviving
-// bit is tested with the exact predicates.
+// ---------------------------------------------------------------------------------------------------------------------
+// Apex search by sweeps.  Candidates c on side dir of the edge s -> a are ranked by the parameter of their circle,
+//     lambda(c) = (|c|^2 - a.c) / (2 |D|),   D = a x c   (coordinates relative to s),
+// the signed position of the circle's centre along the edge's bisector: c1 lies inside circle(s, a, c2) iff
+// lambda(c1) < lambda(c2).  Numerator and denominator are integers below 2^24 (coordinates below 2^11), exact in
+// float32, so the float quotient is off by a few ulp at most: two candidates whose lambdas differ by more than
+// SD_LAM_TOL (relative) are ordered by the floats alone, and only near-ties -- co-circular lattice points, mostly --
+// go to the exact perturbed predicate (sd_better, float64).  The circle itself (centre = a/2 + dir lambda n,
+// r^2 = |a|^2 (1/4 + lambda^2), n the left normal of a) costs a handful of float32 operations and is only used to cut
+// the sweeps, always with margins that make the cut region a superset; circles too large for float32 cuts are not cut.
+#define SD_LAM_TOL 2e-6f
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SD_RCP(x) __builtin_amdgcn_rcpf(x)
+#define SD_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define SD_RCP(x) (1.0f / (x))
+#define SD_SQRT(x) sqrtf(x)
+#endif
+
+struct SdBest {
+    int px, py;   // absolute; px < 0: none yet
+    float lam;
+    // the candidate's circle, for cutting sweeps (valid iff bounded): centre (absolute), padded radius, r^2
+    float ox, oy, rpad, r2;
+    bool bounded;
+};
+
 struct SdEdge {
+    int sx, sy, ax, ay, dir;  // the edge (absolute) and the side searched
+    int vx, vy;               // a - s
     // dir * orient(s, a, (x, y)) = P (y - sy) - Q (x - sx) >= 1  <=>  strictly on side dir of s -> a.
     // Small integers (< 2^11), so float32 products are exact; only the quotient is rounded, and the cut keeps a margin.
     float P, Q, invQ;
+    float a2;                 // |a - s|^2
 };
 
 SD_FN SdEdge sd_edge(int sx, int sy, int ax, int ay, int dir) {
     SdEdge e;
-    e.P = (float)(dir * (ax - sx));
-    e.Q = (float)(dir * (ay - sy));
+    e.sx = sx; e.sy = sy; e.ax = ax; e.ay = ay; e.dir = dir;
+    e.vx = ax - sx;
+    e.vy = ay - sy;
+    e.P = (float)(dir * e.vx);
+    e.Q = (float)(dir * e.vy);
     e.invQ = e.Q != 0.f ? 1.0f / e.Q : 0.f;
+    e.a2 = (float)(e.vx * e.vx + e.vy * e.vy);
     return e;
 }
 
-SD_FN void sd_scan_rows(const SdGrid& g, const SdEdge& e, int sx, int sy, int ax, int ay, int dir, int ya, int yb, int step,
-                        int xa, int xb, int* px, int* py, SdCircle* circ) {
-    const bool wide = xb - xa > 48;
+SD_FN void sd_best_set(SdBest& b, const SdEdge& e, int x, int y, float lam) {
+    b.px = x;
+    b.py = y;
+    b.lam = lam;
+    const float r2 = e.a2 * (0.25f + lam * lam);
+    b.r2 = r2;
+    b.bounded = r2 < 6.0e7f;  // r < ~7700 px: float32 places the circle to ~1e-3 px
+    const float t = (float)e.dir * lam;
+    b.ox = (float)e.sx + 0.5f * (float)e.vx - t * (float)e.vy;
+    b.oy = (float)e.sy + 0.5f * (float)e.vy + t * (float)e.vx;
+    b.rpad = SD_SQRT(r2) * 1.00001f + 1.5f;
+}
+
+// lambda of the site (x, y), or false if it is not strictly on the searched side
+SD_FN bool sd_lambda(const SdEdge& e, int x, int y, float* lam) {
+    const int cx = x - e.sx, cy = y - e.sy;
+    const int D = e.vx * cy - e.vy * cx;
+    if (e.dir > 0 ? D <= 0 : D >= 0) return false;
+    const int N = cx * cx + cy * cy - (e.vx * cx + e.vy * cy);
+    *lam = (float)N * SD_RCP((float)(2 * (D < 0 ? -D : D)));
+    return true;
+}
+
+// does candidate (x, y, lam) beat the current best?  floats when they are decisive, the exact predicate otherwise
+SD_FN bool sd_beats(const SdEdge& e, const SdBest& b, int x, int y, float lam) {
+    if (b.px < 0) return true;
+    const float tol = SD_LAM_TOL * (fabsf(lam) + fabsf(b.lam)) + 1e-30f;
+    if (lam < b.lam - tol) return true;
+    if (lam > b.lam + tol) return false;
+    if (x == b.px && y == b.py) return false;
+    SD_COUNT(exact);
+    return sd_better(e.sx, e.sy, e.ax, e.ay, b.px, b.py, x, y, e.dir);
+}
+
+// Scan rows ya, ya+step, ..., yb (step = +1 or -1), columns [xa, xb], for a better apex.  Rows are cut to their
+// occupied extent and, before the bitmap is touched, to the open half-plane on the searched side and to the current
+// candidate circle (supersets), so rows on the wrong side cost a few instructions and the work shrinks as the apex
+// improves.  A sweep stops once it has left the circle in its direction of travel.
+SD_FN void sd_scan_rows(const SdGrid& g, const SdEdge& e, int ya, int yb, int step, int xa, int xb, SdBest* best) {
     for (int y = ya + g.lane * step; step > 0 ? y <= yb : y >= yb; y += g.nlanes * step) {
         SD_COUNT(rows);
         int x0 = xa > g.rmin[y] ? xa : g.rmin[y];
         int x1 = xb < g.rmax[y] ? xb : g.rmax[y];
         if (x0 > x1) continue;
-        if (*px >= 0) {
-            const double dy = y - circ->oy;
-            if (dy > circ->rpad || -dy > circ->rpad) {  // |dy| > r + 1
-                if (step > 0 ? dy > 0 : dy < 0) break;             // left the circle for good
+        const bool cut = best->px >= 0 && best->bounded;
+        float dy = 0.f;
+        if (cut) {
+            dy = (float)y - best->oy;
+            if (dy > best->rpad || -dy > best->rpad) {
+                if (step > 0 ? dy > 0.f : dy < 0.f) break;  // left the circle for good
                 continue;
             }
         }
-        if (wide) {
-            const float T = e.P * (float)(y - sy) - 1.0f;  // exact
+        {
+            const float T = e.P * (float)(y - e.sy) - 1.0f;  // exact
             if (e.Q == 0.f) {
                 if (T < 0.f) continue;
             } else {
                 const float t = T * e.invQ;  // Q u <= T  with u = x - sx ; |t| < 2^22, rounding error < 1
                 if (e.Q > 0.f) {
-                    const float hi = floorf(t) + 2.0f + (float)sx;
+                    const float hi = floorf(t) + 2.0f + (float)e.sx;
                     if (hi < (float)x1) x1 = hi < -1.0f ? -1 : (int)hi;
                 } else {
-                    const float lo = ceilf(t) - 2.0f + (float)sx;
+                    const float lo = ceilf(t) - 2.0f + (float)e.sx;
                     if (lo > (float)x0) x0 = lo > 1e9f ? g.W : (int)lo;
                 }
                 if (x0 > x1) continue;
             }
-            if (*px >= 0) {
-                const double dy = y - circ->oy;
-                const double h2 = circ->r2 - dy * dy;
-                // h2 carries a round-off of a few ulp of r^2 (r can reach 2.5e8 px for sliver triangles): widen by it;
-                // a float32 square root (relative error 1e-7, widened as well) is plenty for a superset
-                const double half = (double)sqrtf((float)((h2 > 0 ? h2 : 0.0) + 4e-15 * circ->r2)) * (1.0 + 1e-6) + 1.0;
-                const double lo = floor(circ->ox - half), hi = ceil(circ->ox + half);
-                if (lo > x0) x0 = lo > 1e9 ? g.W : (int)lo;
-                if (hi < x1) x1 = hi < -1e9 ? -1 : (int)hi;
+            if (cut) {
+                const float h2 = best->r2 - dy * dy;
+                // r^2 - dy^2 cancels: widen by its round-off (a few ulp of r^2) before the square root
+                const float half = SD_SQRT((h2 > 0.f ? h2 : 0.f) + 2e-6f * best->r2) * 1.00001f + 1.5f;
+                const float lo = floorf(best->ox - half), hi = ceilf(best->ox + half);
+                if (lo > (float)x0) x0 = (int)lo;
+                if (hi < (float)x1) x1 = (int)hi;
                 if (x0 > x1) continue;
             }
         }
         for (int w = x0 >> 5; w <= (x1 >> 5); w++) {
             uint32_t bits = sd_word_bits(g, y, w, x0, x1);
             while (bits) {
-                int x = (w << 5) + sd_ctz(bits);
+                const int x = (w << 5) + sd_ctz(bits);
                 bits &= bits - 1;
                 SD_COUNT(bits);
-                int32_t o = sd_orient(sx, sy, ax, ay, x, y);
-                if (dir > 0 ? o <= 0 : o >= 0) continue;  // wrong side, collinear, or s / a themselves
-                if (*px >= 0) {  // cheap float reject: clearly outside the candidate circle
-                    const double ex = x - circ->ox, ey = y - circ->oy;
-                    if (ex * ex + ey * ey > circ->r2 * (1.0 + 1e-9) + 1e-3) continue;
-                }
-                SD_COUNT(exact);
-                if (*px < 0 || sd_better(sx, sy, ax, ay, *px, *py, x, y, dir)) {
-                    *px = x;
-                    *py = y;
-                    *circ = sd_circle(sx, sy, ax, ay, x, y);
-                }
+                float lam;
+                if (!sd_lambda(e, x, y, &lam)) continue;  // wrong side, collinear, or s / a themselves
+                if (sd_beats(e, *best, x, y, lam)) sd_best_set(*best, e, x, y, lam);
             }
         }
     }
 }
 
-// Merge the candidates of the lanes that share a sweep: a butterfly of exact comparisons, after which every lane holds
-// the same best apex.  (The order "c beats p" is total under the perturbation, so both partners of an exchange agree.)
-SD_FN void sd_share_best(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int* px, int* py, SdCircle* circ,
-                         int* shared_x, int* shared_y) {
+// Merge the candidates of the lanes that share a sweep, after which every lane holds the same best apex: a float
+// minimum over the wave finds the contenders (lambda within the tolerance of the minimum -- the true best is among them),
+// which are then folded with the exact order (one contender in the common case).
+SD_FN void sd_share_best(const SdGrid& g, const SdEdge& e, SdBest* best, int* shared_x, int* shared_y) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (g.nlanes > 1) {
-        // nothing to merge if no lane improved on the candidate all lanes agreed on last time (the common case for
-        // sweeps outside the window)
-        const unsigned long long changed = __ballot(*px >= 0 && (*px != *shared_x || *py != *shared_y));
+        // nothing to merge if no lane improved on the candidate all lanes agreed on last time
+        const unsigned long long changed = __ballot(best->px >= 0 && (best->px != *shared_x || best->py != *shared_y));
         if (changed == 0ull) return;
-        if (__popcll(changed) <= 8) {
-            // few lanes found something: fold them in one after the other (wave-uniform, no shuffles)
-            int bx = *shared_x, by = *shared_y;
-            unsigned long long m = changed;
-            while (m) {
-                const int l = (int)__ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                const int ox = __builtin_amdgcn_readlane(*px, l), oy = __builtin_amdgcn_readlane(*py, l);
-                if ((ox != bx || oy != by) && (bx < 0 || sd_better(sx, sy, ax, ay, bx, by, ox, oy, dir))) {
-                    bx = ox;
-                    by = oy;
-                }
-            }
-            *px = bx;
-            *py = by;
-        } else {
-            for (int off = 32; off >= 1; off >>= 1) {
-                const int ox = __shfl_xor(*px, off), oy = __shfl_xor(*py, off);
-                const bool differs = ox >= 0 && (ox != *px || oy != *py);
-                if (differs && (*px < 0 || sd_better(sx, sy, ax, ay, *px, *py, ox, oy, dir))) {
-                    *px = ox;
-                    *py = oy;
-                }
-            }
+        // contenders: the lanes that changed (each of their candidates beats the one shared so far); if many did, a
+        // float minimum over the wave thins them out first
+        unsigned long long cont = changed;
+        if (__popcll(changed) > 4) {
+            float m = best->px >= 0 ? best->lam : 3.0e38f;
+            for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+            const float tol = 2.f * SD_LAM_TOL * fabsf(m) + 1e-30f;
+            cont = __ballot(best->px >= 0 && best->lam <= m + 2.f * tol);
         }
-        if (*px >= 0) *circ = sd_circle(sx, sy, ax, ay, *px, *py);
-        *shared_x = *px;
-        *shared_y = *py;
+        SdBest w;
+        w.px = -1; w.py = -1; w.lam = 0.f; w.ox = w.oy = w.rpad = w.r2 = 0.f; w.bounded = false;
+        while (cont) {
+            const int l = (int)__ffsll((long long)cont) - 1;
+            cont &= cont - 1ull;
+            const int ox = __builtin_amdgcn_readlane(best->px, l), oy = __builtin_amdgcn_readlane(best->py, l);
+            const float ol = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(best->lam), l));
+            if (sd_beats(e, w, ox, oy, ol)) { w.px = ox; w.py = oy; w.lam = ol; }
+        }
+        sd_best_set(*best, e, w.px, w.py, w.lam);
+        *shared_x = w.px;
+        *shared_y = w.py;
     }
 #else
-    (void)g; (void)sx; (void)sy; (void)ax; (void)ay; (void)dir; (void)px; (void)py; (void)circ; (void)shared_x; (void)shared_y;
+    (void)g; (void)e; (void)best; (void)shared_x; (void)shared_y;
 #endif
 }
 
 #ifndef SD_WINDOW_MARGIN
-#define SD_WINDOW_MARGIN 2
+#define SD_WINDOW_MARGIN 6
 #endif
 
 // Apex of the Delaunay triangle on side dir of the Delaunay edge s->a.  Returns false iff there is no site
 // strictly on that side, i.e. s->a is a hull edge.
 SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int* outx, int* outy) {
-    int px = -1, py = -1, shx = -1, shy = -1;  // shx, shy: the candidate all sharing lanes last agreed on
-    SdCircle circ = {0, 0, 0, 0};
-    const SdEdge edge = sd_edge(sx, sy, ax, ay, dir);
     SD_COUNT(apex);
     long long lap = SD_NOW();
     // 0. short edge: the pre-sorted candidate table answers with bitmap probes alone.  (Side -1 of s->a is side +1 of
@@ -343,6 +388,13 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         }
     }
     if (sd_side_is_empty(g, sx, sy, ax, ay, dir)) return false;
+    const SdEdge edge = sd_edge(sx, sy, ax, ay, dir);
+    SdBest best;
+    best.px = best.py = -1;
+    best.lam = 0.f;
+    best.ox = best.oy = best.rpad = best.r2 = 0.f;
+    best.bounded = false;
+    int shx = -1, shy = -1;  // the candidate all sharing lanes last agreed on
     // 1. a small window around the edge finds the apex in dense regions; while it finds nothing it is widened
     //    threefold (clipped to the bounding box of the sites).  Searching outwards keeps the first candidates few:
     //    the previous, smaller window was empty, and every candidate found shrinks the circle for the others.
@@ -356,9 +408,9 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         if (wx0 < g.bx0) wx0 = g.bx0;
         if (wy1 > g.by1) wy1 = g.by1;
         if (wx1 > g.bx1) wx1 = g.bx1;
-        sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0, wy1, 1, wx0, wx1, &px, &py, &circ);
-        sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
-        if (px >= 0) break;
+        sd_scan_rows(g, edge, wy0, wy1, 1, wx0, wx1, &best);
+        sd_share_best(g, edge, &best, &shx, &shy);
+        if (best.px >= 0) break;
         if (wy0 <= g.by0 && wx0 <= g.bx0 && wy1 >= g.by1 && wx1 >= g.bx1) {
             SD_LAP(far, lap);
             return false;
@@ -367,27 +419,28 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         M = 3 * M + 2;
     }
     SD_LAP(window, lap);
-    if (px >= 0) {
-        // 2. whatever part of the candidate's circle sticks out of the window (and is on the image) is swept too
-        const double r = circ.rpad;
-        const double fy0 = circ.oy - r, fy1 = circ.oy + r, fx0 = circ.ox - r, fx1 = circ.ox + r;
-        const int cy0 = fy0 <= 0 ? 0 : (int)fy0, cx0 = fx0 <= 0 ? 0 : (int)fx0;
-        const int cy1 = fy1 >= g.H - 1 ? g.H - 1 : (int)fy1 + 1, cx1 = fx1 >= g.W - 1 ? g.W - 1 : (int)fx1 + 1;
+    {
+        // 2. whatever part of the candidate's circle sticks out of the window (and holds sites) is swept too
+        int cy0 = g.by0, cy1 = g.by1, cx0 = g.bx0, cx1 = g.bx1;
+        if (best.bounded) {
+            const float fy0 = floorf(best.oy - best.rpad), fy1 = ceilf(best.oy + best.rpad);
+            const float fx0 = floorf(best.ox - best.rpad), fx1 = ceilf(best.ox + best.rpad);
+            if (fy0 > (float)cy0) cy0 = (int)fy0;
+            if (fx0 > (float)cx0) cx0 = (int)fx0;
+            if (fy1 < (float)cy1) cy1 = (int)fy1;
+            if (fx1 < (float)cx1) cx1 = (int)fx1;
+        }
         if (cy1 > wy1 || cy0 < wy0 || cx0 < wx0 || cx1 > wx1) {
             SD_COUNT(apex_slow);
-            if (cy1 > wy1) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy1 + 1, cy1, 1, cx0, cx1, &px, &py, &circ);
-            sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
-            if (cy0 < wy0) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, wy0 - 1, cy0, -1, cx0, cx1, &px, &py, &circ);
-            const int ry0 = cy0 > wy0 ? cy0 : wy0, ry1 = cy1 < wy1 ? cy1 : wy1;
-            if (cx0 < wx0) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, ry0, ry1, 1, cx0, wx0 - 1, &px, &py, &circ);
-            if (cx1 > wx1) sd_scan_rows(g, edge, sx, sy, ax, ay, dir, ry0, ry1, 1, wx1 + 1, cx1, &px, &py, &circ);
-            sd_share_best(g, sx, sy, ax, ay, dir, &px, &py, &circ, &shx, &shy);
+            // one sweep over the circle's rows: what the window already covered is cut away by the circle, cheaply
+            sd_scan_rows(g, edge, cy0, cy1, 1, cx0, cx1, &best);
+            sd_share_best(g, edge, &best, &shx, &shy);
         }
         SD_LAP(slow, lap);
     }
-    *outx = px;
-    *outy = py;
-    return px >= 0;
+    *outx = best.px;
+    *outy = best.py;
+    return true;
 }
 
 #define SD_MAX_DEGREE 8192  // safety bound on the wrap loop; a lattice site cannot have more neighbours than this
