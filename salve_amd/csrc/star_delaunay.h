@@ -134,7 +134,8 @@ SD_FN int sd_ctz(uint32_t v) {
 #endif
 }
 
-// Nearest site to s (any one of the nearest on ties).  Returns false iff s is the only site.
+// Nearest site to s (on ties: any one of the nearest, chosen deterministically).  Returns false iff s is the only site.
+// Lanes that share the search take rows lane, lane + nlanes, ... of each window and merge by a wave minimum.
 SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
     int32_t best = INT32_MAX;
     int bx = -1, by = -1;
@@ -142,7 +143,7 @@ SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
     for (;;) {
         int y0 = sy - R < 0 ? 0 : sy - R, y1 = sy + R > g.H - 1 ? g.H - 1 : sy + R;
         int x0 = sx - R < 0 ? 0 : sx - R, x1 = sx + R > g.W - 1 ? g.W - 1 : sx + R;
-        for (int y = y0; y <= y1; y++) {
+        for (int y = y0 + g.lane; y <= y1; y += g.nlanes) {
             if (g.rmax[y] < x0 || g.rmin[y] > x1) continue;
             for (int w = x0 >> 5; w <= (x1 >> 5); w++) {
                 uint32_t bits = sd_word_bits(g, y, w, x0, x1);
@@ -155,6 +156,22 @@ SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
                 }
             }
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (g.nlanes > 1) {
+            int32_t m = best;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int32_t o = __shfl_xor(m, off);
+                m = o < m ? o : m;
+            }
+            if (m != INT32_MAX) {  // the lowest lane holding the minimum
+                const unsigned long long who = __ballot(best == m);
+                const int l = (int)__ffsll((long long)who) - 1;
+                bx = __builtin_amdgcn_readlane(bx, l);
+                by = __builtin_amdgcn_readlane(by, l);
+            }
+            best = m;
+        }
+#endif
         if (best <= R * R) break;                                   // nothing outside the window is closer
         if (x0 == 0 && y0 == 0 && x1 == g.W - 1 && y1 == g.H - 1) break;    // whole image searched
         R *= 2;
@@ -259,13 +276,14 @@ SD_FN bool sd_beats(const SdEdge& e, const SdBest& b, int x, int y, float lam) {
 // occupied extent and, before the bitmap is touched, to the open half-plane on the searched side and to the current
 // candidate circle (supersets), so rows on the wrong side cost a few instructions and the work shrinks as the apex
 // improves.  A sweep stops once it has left the circle in its direction of travel.
+template <bool CUTS>
 SD_FN void sd_scan_rows(const SdGrid& g, const SdEdge& e, int ya, int yb, int step, int xa, int xb, SdBest* best) {
     for (int y = ya + g.lane * step; step > 0 ? y <= yb : y >= yb; y += g.nlanes * step) {
         SD_COUNT(rows);
         int x0 = xa > g.rmin[y] ? xa : g.rmin[y];
         int x1 = xb < g.rmax[y] ? xb : g.rmax[y];
         if (x0 > x1) continue;
-        const bool cut = best->px >= 0 && best->bounded;
+        const bool cut = CUTS && best->px >= 0 && best->bounded;
         float dy = 0.f;
         if (cut) {
             dy = (float)y - best->oy;
@@ -307,7 +325,15 @@ SD_FN void sd_scan_rows(const SdGrid& g, const SdEdge& e, int ya, int yb, int st
                 SD_COUNT(bits);
                 float lam;
                 if (!sd_lambda(e, x, y, &lam)) continue;  // wrong side, collinear, or s / a themselves
-                if (sd_beats(e, *best, x, y, lam)) sd_best_set(*best, e, x, y, lam);
+                if (sd_beats(e, *best, x, y, lam)) {
+                    if (CUTS) {
+                        sd_best_set(*best, e, x, y, lam);
+                    } else {  // small window: the circle is only needed after the merge (sd_share_best sets it)
+                        best->px = x;
+                        best->py = y;
+                        best->lam = lam;
+                    }
+                }
             }
         }
     }
@@ -408,7 +434,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         if (wx0 < g.bx0) wx0 = g.bx0;
         if (wy1 > g.by1) wy1 = g.by1;
         if (wx1 > g.bx1) wx1 = g.bx1;
-        sd_scan_rows(g, edge, wy0, wy1, 1, wx0, wx1, &best);
+        sd_scan_rows<false>(g, edge, wy0, wy1, 1, wx0, wx1, &best);
         sd_share_best(g, edge, &best, &shx, &shy);
         if (best.px >= 0) break;
         if (wy0 <= g.by0 && wx0 <= g.bx0 && wy1 >= g.by1 && wx1 >= g.bx1) {
@@ -418,6 +444,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         SD_COUNT(apex_far);
         M = 3 * M + 2;
     }
+    if (g.nlanes == 1) sd_best_set(best, edge, best.px, best.py, best.lam);  // (a merge sets the circle itself)
     SD_LAP(window, lap);
     {
         // 2. whatever part of the candidate's circle sticks out of the window (and holds sites) is swept too
@@ -433,7 +460,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         if (cy1 > wy1 || cy0 < wy0 || cx0 < wx0 || cx1 > wx1) {
             SD_COUNT(apex_slow);
             // one sweep over the circle's rows: what the window already covered is cut away by the circle, cheaply
-            sd_scan_rows(g, edge, cy0, cy1, 1, cx0, cx1, &best);
+            sd_scan_rows<true>(g, edge, cy0, cy1, 1, cx0, cx1, &best);
             sd_share_best(g, edge, &best, &shx, &shy);
         }
         SD_LAP(slow, lap);
