@@ -114,11 +114,13 @@ class RenderVerifyPipeline:
         hb, jb = _lib.HYP_DTYPE.itemsize, _lib.TILE_JOB_DTYPE.itemsize
         rows = prepared["rows"][lo * S * hb:]
         bev, tiles = self.bevs[buf], self.tile_bufs[buf]
-        if timers is not None:
+        if timers is not None:  # benchmark: bracket the densify launch of this chunk with HIP events on its own stream
             self.ras.scatter(self.pano_rgb, self.pano_depth, rows, n * S)
-            timers[0].record()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             self.ras.densify(n * S, bev)
-            timers[1].record()
+            e1.record()
+            timers.append((e0, e1, n * S))
         else:
             self.ras.render(self.pano_rgb, self.pano_depth, rows, n * S, out_bev=bev)
         self.ras.tiles(bev, prepared["jobs1"][lo * S * jb:], n * S, tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
@@ -126,7 +128,8 @@ class RenderVerifyPipeline:
 
     def score(self, prepared, out: Optional[torch.Tensor] = None, timers=None) -> torch.Tensor:
         """Render + verify every hypothesis of a prepared shard.  Returns fp32 logits [N, num_classes].
-        `timers` = (event, event): bracket the densify launch of the first chunk (benchmark roofline)."""
+        `timers` = list: receives (start event, end event, renders) for the densify launch of every chunk (benchmark
+        roofline; the events are recorded on the stream the kernel is launched on)."""
         N = prepared["n"]
         if out is None:
             out = torch.empty((N, self.engine.num_classes), dtype=torch.float32, device=self.device)
@@ -134,7 +137,6 @@ class RenderVerifyPipeline:
         if self.render_stream is None:
             for lo, n in chunks:
                 self._render_chunk(prepared, lo, n, 0, timers)
-                timers = None
                 self.engine.forward_nhwc(self.tile_bufs[0][:n], out=out[lo:lo + n])
             return out
         main = torch.cuda.current_stream(self.device)
@@ -146,7 +148,6 @@ class RenderVerifyPipeline:
                 if i >= self.nbuf:
                     self.render_stream.wait_event(consumed[i - self.nbuf])  # the verifier is done with this buffer set
                 self._render_chunk(prepared, lo, n, i % self.nbuf, timers)
-                timers = None
                 rendered[i].record(self.render_stream)
             main.wait_event(rendered[i])
             self.engine.forward_nhwc(self.tile_bufs[i % self.nbuf][:n], out=out[lo:lo + n])
