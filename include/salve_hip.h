@@ -104,7 +104,8 @@ int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rg
                            int32_t* dbg_stats, int32_t* out_in_window, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The two halves of salve_bev_render_batch as separate launches (same arguments, same workspace):
- * salve_bev_scatter fills the z-order key images, salve_bev_densify turns them into BEV images.  Used by the
+ * salve_bev_scatter fills the z-order key images (winning point index per pixel; the colours stay in pano_rgb, which
+ * must remain valid until salve_bev_densify has run), salve_bev_densify turns them into BEV images.  Used by the
  * benchmark to time the dominant kernel on its own; render_batch == scatter followed by densify. */
 int salve_bev_scatter(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth, int32_t n_panos,
                       const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, int16_t* dbg_img_xy, void* workspace,
@@ -114,7 +115,8 @@ int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_be
 
 /* Splat an explicit coloured point cloud -- the `xyzrgb` argument of render_bev_image (bev_rendering_utils.py:254-308):
  * xyz device double [n_points, 3] in the world frame, rgb device uint8 [n_points, 3] (the reference's float colours
- * already truncated to uint8, :307-308).  Fills key image 0 of the workspace; follow with salve_bev_densify(cfg, 1, ...).
+ * already truncated to uint8, :307-308).  Fills key image 0 of the workspace; follow with salve_bev_densify(cfg, 1, ...),
+ * which reads the winners' colours from `rgb` (keep it alive until then).
  * n_in_window (device int32) receives the number of points inside the window (0 => render_bev_image returns None, :279). */
 int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, const uint8_t* rgb, int32_t n_points,
                              int32_t* n_in_window, void* workspace, size_t workspace_bytes, void* stream);
@@ -126,8 +128,9 @@ int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, c
  * salve_remove_hallucinated: interpolation_utils.remove_hallucinated_content (salve/utils/interpolation_utils.py:74-122) --
  *   sparse / interp / out device uint8 [H,W,3], scratch device uint8 [H*W].
  * salve_bev_keys_from_pixels: the input side of interpolation_utils.interp_dense_grid_from_sparse (:21-54) -- xy device
- *   int32 [n,2] (x, y) pixels, rgb device uint8 [n,3]; fills key image 0; follow with salve_bev_densify(cfg, 1, ...) using
- *   cfg.out_flags = 3 (no flip, no mask) to obtain the interpolated image. */
+ *   int32 [n,2] (x, y) pixels, rgb device uint8 [n,3] (kept alive until the densify call, which reads the colours from
+ *   it); fills key image 0; follow with salve_bev_densify(cfg, 1, ...) using cfg.out_flags = 3 (no flip, no mask) to
+ *   obtain the interpolated image. */
 int salve_zorder_winners(const int32_t* x, const int32_t* y, const double* z, int32_t n, const double* planes, int32_t n_slices,
                          int32_t img_w, int32_t img_h, uint64_t* scratch, uint8_t* valid, void* stream);
 int salve_remove_hallucinated(const uint8_t* sparse, const uint8_t* interp, int32_t H, int32_t W, int32_t K, uint8_t* scratch,

@@ -2,14 +2,15 @@
 //
 // One render = one panorama surface under one Sim(2) pose -> one 501x501 BEV image.  Three kernels:
 //
-//   bev_scatter_kernel   (HBM-streaming)  pano RGB u8 + depth u16 -> back-project, pose, prune, round to BEV pixel,
-//                        z-order splat by 64-bit atomicMax into an L2-resident key image [bev_h*bev_w] u64.
+//   bev_scatter_kernel   (HBM-streaming)  pano depth u16 -> back-project, pose, prune, round to BEV pixel,
+//                        z-order splat by 32-bit atomicMax into a key image [bev_h*bev_w] u32 (slice, point index).
 //                        Reference: bev_rendering_utils.py:367-413 (back-projection), :443-451 (pose),
 //                        :274-287 (prune + pixel index), zorder_utils.py:10-83 (winner), :307-308 (sparse image).
-//   bev_densify_kernel   (LDS/VALU)  one workgroup per render: occupancy + "non-empty" bitmaps in LDS (2 x 32 KB),
-//                        11x11 dilation mask on the bitmaps, then every site walks its own Delaunay star
-//                        (star_delaunay.h) and rasterises the triangles it owns with exact rational barycentric
-//                        weights.  Reference: interpolation_utils.py:21-54 (griddata linear), :74-122 (mask),
+//   bev_densify_kernel   (LDS/VALU)  one workgroup per render: reads the key image once (colour of each winner
+//                        gathered from its panorama), occupancy + "non-empty" bitmaps in LDS (2 x 32 KB), 11x11
+//                        dilation mask on the bitmaps, then every site walks its own Delaunay star (star_local.h,
+//                        star_delaunay.h) and the owned triangles are rasterised with exact rational barycentric
+//                        weights into the output image, which is written once.  Reference: interpolation_utils.py:21-54 (griddata linear), :74-122 (mask),
 //                        bev_rendering_utils.py:318-319 (mask multiply, flipud).
 //   bev_tile_kernel      BEV -> verifier input tile (resize 234, crop 224, normalise).  Reference:
 //                        train_utils.py:126-159, transform.py:256-272, 386-420, 105-123, 177-202.
@@ -47,6 +48,11 @@ constexpr int PTS_PER_THREAD = 4;
 constexpr int DENSIFY_THREADS = 512;
 constexpr int MASK_ROWS_PER_TASK = 16;
 constexpr int MASK_MAX_HALF = 8;
+// z-order key of a pixel: (unit slice + 1) << 21 | point index.  atomicMax keeps the highest slice and, within it, the
+// last point in raster order (zorder_utils.py:10-83 + "last index wins" of the sparse image); 0 = no point.  The
+// colour is NOT in the key: the densify kernel fetches it from the point's source array by index.
+constexpr int KEY_SLICE_SHIFT = 21;
+constexpr uint32_t KEY_INDEX_MASK = (1u << KEY_SLICE_SHIFT) - 1u;
 
 struct DevCfg {
     int pano_h, pano_w, crop_rows, rows, npts;
@@ -63,10 +69,12 @@ struct DevCfg {
 // ------------------------------------------------------------------------------------------------ scatter
 __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
     DevCfg c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, const double* __restrict__ sphere,
-    const salve_bev_hyp_t* __restrict__ hyps, unsigned long long* __restrict__ keys, int16_t* __restrict__ dbg_xy,
-    int32_t* __restrict__ in_window) {
+    const salve_bev_hyp_t* __restrict__ hyps, uint32_t* __restrict__ keys, const uint8_t** __restrict__ colour_src,
+    int16_t* __restrict__ dbg_xy, int32_t* __restrict__ in_window) {
     const int rid = blockIdx.y;
     const salve_bev_hyp_t h = hyps[rid];
+    // where the densify kernel finds the colour of point index i of this render: colour_src[rid] + 3 i
+    if (blockIdx.x == 0 && threadIdx.x == 0) colour_src[rid] = rgb + ((size_t)h.pano_idx * c.pano_h + c.crop_rows) * c.pano_w * 3;
     const int p0 = (blockIdx.x * SCATTER_THREADS + threadIdx.x) * PTS_PER_THREAD;  // first point (cropped raster)
     if (p0 >= c.npts) return;
     const int v = p0 / c.pano_w + c.crop_rows;
@@ -80,16 +88,12 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
     const double rv = rr[v], zv = zd[v];
 
     const uint2 dq = *reinterpret_cast<const uint2*>(depth + pix);  // 4 x u16
-    const uint32_t* rgbw = reinterpret_cast<const uint32_t*>(rgb + pix * 3);
-    const uint32_t w0 = rgbw[0], w1 = rgbw[1], w2 = rgbw[2];  // 12 bytes = 4 pixels
-    const uint32_t col[4] = {w0 & 0xFFFFFFu, (w0 >> 24) | ((w1 & 0xFFFFu) << 8), (w1 >> 16) | ((w2 & 0xFFu) << 16),
-                             w2 >> 8};
     const uint32_t dep[4] = {dq.x & 0xFFFFu, dq.x >> 16, dq.y & 0xFFFFu, dq.y >> 16};
 
     const double zlo = c.zlo[h.surface], zhi = c.zhi[h.surface];
     const double R00 = (double)h.R[0], R01 = (double)h.R[1], R10 = (double)h.R[2], R11 = (double)h.R[3];
     const double tx = (double)(h.t[0] * 1.5f), ty = (double)(h.t[1] * 1.5f);  // float32 product, then widened
-    unsigned long long* kimg = keys + (size_t)rid * c.H * c.W;
+    uint32_t* kimg = keys + (size_t)rid * c.H * c.W;
 
 #pragma unroll
     for (int k = 0; k < PTS_PER_THREAD; k++) {
@@ -119,9 +123,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
                 if (in_window) atomicAdd(in_window + rid, 1);
                 const double zs = floor(z) - c.zmin;  // unit slices from an integer z_min: exact
                 if (zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H) {
-                    const unsigned long long key = ((unsigned long long)((int)zs + 1) << 45) |
-                                                   ((unsigned long long)(p0 + k) << 24) | col[k];
-                    atomicMax(kimg + (size_t)iy * c.W + ix, key);
+                    atomicMax(kimg + (size_t)iy * c.W + ix, ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | (uint32_t)(p0 + k));
                 }
             }
         }
@@ -137,9 +139,10 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
 // no back-projection and no pose; prune -> pixel index -> z-order key.  The point's position in the list is its index.
 __global__ __launch_bounds__(256) void bev_scatter_points_kernel(DevCfg c, const double* __restrict__ xyz,
                                                                  const uint8_t* __restrict__ rgb, int npts,
-                                                                 unsigned long long* __restrict__ kimg,
+                                                                 uint32_t* __restrict__ kimg, const uint8_t** __restrict__ colour_src,
                                                                  int* __restrict__ n_in_window) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) colour_src[0] = rgb;
     if (i >= npts) return;
     const double x1 = xyz[3 * (size_t)i], y1 = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
     if (!(c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax)) return;
@@ -148,8 +151,7 @@ __global__ __launch_bounds__(256) void bev_scatter_points_kernel(DevCfg c, const
     const int iy = (int)rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
     const double zs = floor(z) - c.zmin;
     if (!(zs >= 0.0 && zs < (double)c.nslices) || ix < 0 || ix >= c.W || iy < 0 || iy >= c.H) return;
-    const uint32_t col = (uint32_t)rgb[3 * (size_t)i] | ((uint32_t)rgb[3 * (size_t)i + 1] << 8) | ((uint32_t)rgb[3 * (size_t)i + 2] << 16);
-    atomicMax(kimg + (size_t)iy * c.W + ix, ((unsigned long long)((int)zs + 1) << 45) | ((unsigned long long)i << 24) | col);
+    atomicMax(kimg + (size_t)iy * c.W + ix, ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | (uint32_t)i);
 }
 
 // ------------------------------------------------------------------------------------------------ densify
@@ -157,8 +159,7 @@ struct RasterEmit {
     int H, W, wpr;
     const uint32_t* occ;
     const uint32_t* msk;
-    const unsigned long long* keys;
-    uint32_t* bev;  // output image of this render
+    uint32_t* bev;  // output image of this render; the data pixels (triangle vertices) already hold their colours
     int flip;       // H - 1 to flip vertically (np.flipud), -1: no flip
     int lane, nlanes;  // rows lane, lane + nlanes, ... of the bounding box (several lanes may share one triangle)
     bool skip;
@@ -226,11 +227,11 @@ struct RasterEmit {
                     const int32_t wc = area - wa - wb;
                     if ((wa | wb | wc) < 0) continue;
                     if (!have) {
-                        // the key image is rewritten by every launch at the same addresses: read it past the L1,
-                        // which may still hold the previous launch's lines when kernels of two streams interleave
-                        ca = (uint32_t)__hip_atomic_load(keys + (size_t)ay * W + ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFu;
-                        cb = (uint32_t)__hip_atomic_load(keys + (size_t)by * W + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFu;
-                        cc = (uint32_t)__hip_atomic_load(keys + (size_t)cy * W + cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFu;
+                        // vertex colours from the output image, where phase B of this workgroup put them: read past
+                        // the L1 (the stores went to L2; the L1 may hold older lines of these addresses)
+                        ca = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - ay : ay) * W + ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        cb = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - by : by) * W + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        cc = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - cy : cy) * W + cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         have = true;
                     }
                     bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = blend(wa, wb, wc, area, ca, cb, cc);
@@ -272,7 +273,7 @@ __device__ __forceinline__ void wg_barrier_after_global_stores() {
     __syncthreads();
 }
 
-__device__ __forceinline__ unsigned long long load_key(const unsigned long long* p) {
+__device__ __forceinline__ uint32_t load_key(const uint32_t* p) {
     // keys were produced by L2 atomics of another kernel / by this workgroup's peers: read them past the L1
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -297,7 +298,7 @@ static int ensure_star_table() {
 }
 
 __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
-    DevCfg c, const unsigned long long* __restrict__ keys_all, uint32_t* __restrict__ bev_all,
+    DevCfg c, const uint32_t* __restrict__ keys_all, const uint8_t* const* __restrict__ colour_src, uint32_t* __restrict__ bev_all,
     uint32_t* __restrict__ sitelist_all, uint32_t* __restrict__ hardlist_all, unsigned long long* __restrict__ triq_all,
     uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats, int16_t* __restrict__ dbg_aux) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -310,7 +311,9 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     int* scal = reinterpret_cast<int*>(rmax + Hp);  // [0] n_sites [1] min x [2] max x [3] rows [4] steps [5] err
 
     const int rid = blockIdx.x;
-    const unsigned long long* keys = keys_all + (size_t)rid * H * W;
+    const uint32_t* keys = keys_all + (size_t)rid * H * W;
+    const uint8_t* colours = colour_src[rid];
+    const int flip = (c.out_flags & 1) ? -1 : H - 1;
     uint32_t* bev = bev_all + (size_t)rid * H * W;
     uint32_t* sitelist = sitelist_all + (size_t)rid * H * W;
     uint32_t* hardlist = hardlist_all + (size_t)rid * H * W;
@@ -335,10 +338,18 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             unsigned long long ob = 0, ne_next = 0;
             if (seg < nseg) {
                 const int x = (seg << 6) + lane;
-                unsigned long long key = 0;
+                uint32_t key = 0;
                 if (x < W) key = load_key(keys + (size_t)y * W + x);
                 const bool site = key != 0;
-                const uint32_t r = (uint32_t)key & 255u, gch = ((uint32_t)key >> 8) & 255u, b = ((uint32_t)key >> 16) & 255u;
+                uint32_t col = 0;
+                if (site) {  // the winning point's colour, from its source array (panorama or point list: L2-resident)
+                    const uint8_t* cs = colours + 3 * (size_t)(key & KEY_INDEX_MASK);
+                    col = (uint32_t)cs[0] | ((uint32_t)cs[1] << 8) | ((uint32_t)cs[2] << 16);
+                }
+                // the output image starts as the sparse image: data pixels carry their colour (they are also the vertex
+                // colours the rasteriser reads back), everything else is 0
+                if (x < W) bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = col;
+                const uint32_t r = col & 255u, gch = (col >> 8) & 255u, b = (col >> 16) & 255u;
                 const bool ne = site && (((r * gch * b) & 255u) != 0);
                 ob = __ballot(site);
                 ne_next = __ballot(ne);
@@ -421,19 +432,6 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     // interp_dense_grid_from_sparse early-outs (interpolation_utils.py:39-43): < 4 points, all x equal, all y equal
     const bool degenerate = nsites < 4 || scal[1] == scal[2] || scal[3] <= 1;
 
-    // ---- phase D: base image = data pixels under the mask (at a data pixel the interpolant is the datum), 0 elsewhere.
-    for (int y = wave; y < H; y += nwaves) {
-        for (int seg = 0; seg < nseg; seg++) {
-            const int x = (seg << 6) + lane;
-            if (x >= W) continue;
-            const uint32_t ow = occ[y * wpr + (x >> 5)], mw = msk[y * wpr + (x >> 5)];
-            const bool m = (mw >> (x & 31)) & 1u;
-            uint32_t val = 0;
-            if (!degenerate && m && ((ow >> (x & 31)) & 1u)) val = (uint32_t)load_key(keys + (size_t)y * W + x) & 0xFFFFFFu;
-            bev[(size_t)((c.out_flags & 1) ? y : H - 1 - y) * W + x] = val;
-            if (dbg_mask) dbg_mask[((size_t)rid * H + y) * W + x] = m ? 1 : 0;
-        }
-    }
     // the site list and the base image were written by this workgroup through L2: make them visible to all its waves
     wg_barrier_after_global_stores();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -445,7 +443,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     //          in place.   F: all lanes rasterise the queued triangles.
     if (!degenerate && !(c.dbg_flags & 1)) {
         SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13]};
-        RasterEmit raster = {H, W, wpr, occ, msk, keys, bev, (c.out_flags & 1) ? -1 : H - 1, 0, 1, (c.dbg_flags & 2) != 0};
+        RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (c.dbg_flags & 2) != 0};
         QueueEmit qemit = {triq, &scal[8], H * W, raster};
         SdLean st;
         bool active = false, exhausted = false;
@@ -513,6 +511,24 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             const uint32_t rel = (uint32_t)(e >> 32);
             raster(ax, ay, ax + (int8_t)(rel & 0xFF), ay + (int8_t)((rel >> 8) & 0xFF), ax + (int8_t)((rel >> 16) & 0xFF),
                    ay + (int8_t)(rel >> 24));
+        }
+    }
+    // ---- phase G: data pixels outside the mask are 0 in the result (all of them if the interpolation early-outs).
+    //      They kept their colour until here because triangles read their vertex colours from the image.
+    wg_barrier_after_global_stores();
+    for (int i = tid; i < H * wpr; i += DENSIFY_THREADS) {
+        uint32_t bits = occ[i] & (degenerate ? 0xFFFFFFFFu : ~msk[i]);
+        const int y = i / wpr, xb = (i % wpr) << 5;
+        while (bits) {
+            const int x = xb + __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = 0u;
+        }
+    }
+    if (dbg_mask) {
+        for (int i = tid; i < H * W; i += DENSIFY_THREADS) {
+            const int y = i / W, x = i % W;
+            dbg_mask[(size_t)rid * H * W + i] = (uint8_t)((msk[y * wpr + (x >> 5)] >> (x & 31)) & 1u);
         }
     }
     if (dbg_stats) {
@@ -635,13 +651,29 @@ __global__ __launch_bounds__(256) void halluc_apply_kernel(const uint8_t* __rest
 
 // interp_dense_grid_from_sparse (:21-54): sites given as pixel coordinates + colours -> key image (last index wins).
 __global__ __launch_bounds__(256) void keys_from_pixels_kernel(const int32_t* __restrict__ xy, const uint8_t* __restrict__ rgb, int n,
-                                                               int W, int H, unsigned long long* __restrict__ kimg) {
+                                                               int W, int H, uint32_t* __restrict__ kimg,
+                                                               const uint8_t** __restrict__ colour_src) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) colour_src[0] = rgb;
     if (i >= n) return;
     const int x = xy[2 * i], y = xy[2 * i + 1];
     if (x < 0 || x >= W || y < 0 || y >= H) return;
-    const uint32_t col = (uint32_t)rgb[3 * (size_t)i] | ((uint32_t)rgb[3 * (size_t)i + 1] << 8) | ((uint32_t)rgb[3 * (size_t)i + 2] << 16);
-    atomicMax(kimg + (size_t)y * W + x, (1ull << 45) | ((unsigned long long)i << 24) | col);
+    atomicMax(kimg + (size_t)y * W + x, (1u << KEY_SLICE_SHIFT) | (uint32_t)i);
+}
+
+// Debug export of the key images in the 64-bit form the tests decode: (slice + 1) << 45 | index << 24 | B G R.
+__global__ __launch_bounds__(256) void keys_export_kernel(const uint32_t* __restrict__ keys, const uint8_t* const* __restrict__ colour_src,
+                                                          size_t npx, size_t total, unsigned long long* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t k = keys[i];
+    unsigned long long v = 0;
+    if (k) {
+        const uint8_t* cs = colour_src[i / npx] + 3 * (size_t)(k & KEY_INDEX_MASK);
+        const uint32_t col = (uint32_t)cs[0] | ((uint32_t)cs[1] << 8) | ((uint32_t)cs[2] << 16);
+        v = ((unsigned long long)(k >> KEY_SLICE_SHIFT) << 45) | ((unsigned long long)(k & KEY_INDEX_MASK) << 24) | col;
+    }
+    out[i] = v;
 }
 
 bool make_devcfg(const salve_bev_config_t* cfg, DevCfg* d) {
@@ -675,11 +707,31 @@ size_t densify_lds_bytes(const DevCfg& d) {
 
 extern "C" {
 
+// Workspace of n renders: triangle queues (8 B / pixel), colour-source pointers (8 B / render), key images, site
+// lists, hard-site lists (4 B / pixel each).
+struct Workspace {
+    unsigned long long* triq;
+    const uint8_t** colour_src;
+    uint32_t* keys;
+    uint32_t* sitelist;
+    uint32_t* hardlist;
+};
+
+static Workspace carve_workspace(void* workspace, size_t n, size_t npx) {
+    Workspace w;
+    w.triq = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    w.colour_src = reinterpret_cast<const uint8_t**>(w.triq + n * npx);
+    w.keys = reinterpret_cast<uint32_t*>(w.colour_src + n);
+    w.sitelist = w.keys + n * npx;
+    w.hardlist = w.sitelist + n * npx;
+    return w;
+}
+
 size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n) {
     DevCfg d;
     if (n <= 0 || !make_devcfg(cfg, &d)) return 0;
     const size_t npx = (size_t)d.H * d.W;
-    return (size_t)n * npx * (2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t)) + 256;
+    return (size_t)n * (npx * (sizeof(unsigned long long) + 3 * sizeof(uint32_t)) + sizeof(void*)) + 256;
 }
 
 static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* pano_rgb, const uint16_t* pano_depth,
@@ -702,18 +754,15 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
     if (lds > 160 * 1024) { salve_fail("bev image does not fit the 160 KB LDS"); return SALVE_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     const size_t npx = (size_t)d.H * d.W;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    unsigned long long* triq = keys + (size_t)n * npx;
-    uint32_t* sitelist = reinterpret_cast<uint32_t*>(triq + (size_t)n * npx);
-    uint32_t* hardlist = sitelist + (size_t)n * npx;
+    const Workspace ws = carve_workspace(workspace, (size_t)n, npx);
 
     if (scatter) {
-        SALVE_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)n * npx * sizeof(unsigned long long), s));
+        SALVE_HIP_CHECK(hipMemsetAsync(ws.keys, 0, (size_t)n * npx * sizeof(uint32_t), s));
         const int pts_per_block = SCATTER_THREADS * PTS_PER_THREAD;
         dim3 g1((d.npts + pts_per_block - 1) / pts_per_block, n);
         if (in_window) SALVE_HIP_CHECK(hipMemsetAsync(in_window, 0, (size_t)n * sizeof(int32_t), s));
-        hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, keys,
-                           dbg_img_xy, in_window);
+        hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, ws.keys,
+                           ws.colour_src, dbg_img_xy, in_window);
         SALVE_HIP_CHECK(hipGetLastError());
     }
     if (densify) {
@@ -725,10 +774,15 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_lds = lds;
         }
-        hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, keys, out_bev, sitelist, hardlist, triq,
-                           dbg_mask, dbg_stats, (d.dbg_flags & 16) ? dbg_img_xy : nullptr);
+        hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, ws.keys, ws.colour_src, out_bev, ws.sitelist,
+                           ws.hardlist, ws.triq, dbg_mask, dbg_stats, (d.dbg_flags & 16) ? dbg_img_xy : nullptr);
         SALVE_HIP_CHECK(hipGetLastError());
-        if (dbg_keys) SALVE_HIP_CHECK(hipMemcpyAsync(dbg_keys, keys, (size_t)n * npx * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+        if (dbg_keys) {
+            const size_t total = (size_t)n * npx;
+            hipLaunchKernelGGL(keys_export_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws.keys, ws.colour_src, npx, total,
+                               reinterpret_cast<unsigned long long*>(dbg_keys));
+            SALVE_HIP_CHECK(hipGetLastError());
+        }
     }
     return SALVE_OK;
 }
@@ -765,12 +819,12 @@ int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, c
     if ((long long)n_points >= (1ll << 21)) { salve_fail("at most 2^21 - 1 points"); return SALVE_ERR_UNSUPPORTED; }
     if (workspace_bytes < salve_bev_workspace_bytes(cfg, 1)) { salve_fail("workspace too small"); return SALVE_ERR_WORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    SALVE_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)d.H * d.W * sizeof(unsigned long long), s));
+    const Workspace ws = carve_workspace(workspace, 1, (size_t)d.H * d.W);
+    SALVE_HIP_CHECK(hipMemsetAsync(ws.keys, 0, (size_t)d.H * d.W * sizeof(uint32_t), s));
     SALVE_HIP_CHECK(hipMemsetAsync(n_in_window, 0, sizeof(int32_t), s));
     if (n_points > 0) {
-        hipLaunchKernelGGL(bev_scatter_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, d, xyz, rgb, n_points, keys,
-                           n_in_window);
+        hipLaunchKernelGGL(bev_scatter_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, d, xyz, rgb, n_points, ws.keys,
+                           ws.colour_src, n_in_window);
         SALVE_HIP_CHECK(hipGetLastError());
     }
     return SALVE_OK;
@@ -815,10 +869,11 @@ int salve_bev_keys_from_pixels(const salve_bev_config_t* cfg, const int32_t* xy,
     if ((long long)n_points >= (1ll << 21)) { salve_fail("at most 2^21 - 1 points"); return SALVE_ERR_UNSUPPORTED; }
     if (workspace_bytes < salve_bev_workspace_bytes(cfg, 1)) { salve_fail("workspace too small"); return SALVE_ERR_WORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    SALVE_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)d.H * d.W * sizeof(unsigned long long), s));
+    const Workspace ws = carve_workspace(workspace, 1, (size_t)d.H * d.W);
+    SALVE_HIP_CHECK(hipMemsetAsync(ws.keys, 0, (size_t)d.H * d.W * sizeof(uint32_t), s));
     if (n_points > 0) {
-        hipLaunchKernelGGL(keys_from_pixels_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, xy, rgb, n_points, d.W, d.H, keys);
+        hipLaunchKernelGGL(keys_from_pixels_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, xy, rgb, n_points, d.W, d.H, ws.keys,
+                           ws.colour_src);
         SALVE_HIP_CHECK(hipGetLastError());
     }
     return SALVE_OK;
