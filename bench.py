@@ -28,9 +28,9 @@ PANO_H, PANO_W, CROP = 512, 1024, 80
 BYTES_PER_RENDER = (PANO_H - 2 * CROP) * PANO_W * (3 + 2) + 501 * 501 * 3  # RGB u8 + depth u16 read, BEV u8 written
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes of one bev_densify_kernel launch of 512 renders from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate
-# passes, KiB units; profiles/r01_pmc_traffic.md).  The kernel reads 8 B / lane, for which FETCH_SIZE is uncalibrated:
+# passes, KiB units; profiles/r01_pmc_traffic.md).  The kernel reads 4 B / lane, for which FETCH_SIZE is uncalibrated:
 # the read side is taken as counted (lower bound).
-DENSIFY_TRAFFIC_BYTES_512 = (1243334 + 1069344) * 1024
+DENSIFY_TRAFFIC_BYTES_512 = (610310 + 1053995) * 1024
 
 
 def cpu_baseline(n_hyp: int, procs: int):
