@@ -18,5 +18,6 @@ def install_as_salve() -> None:
     sys.modules.setdefault("salve", sys.modules[__name__])
     for name in ("utils", "common", "models", "utils.bev_rendering_utils", "utils.hohonet_pano_utils", "utils.rotation_utils",
                  "utils.normalization_utils", "utils.mesh_grid", "utils.zorder_utils", "utils.interpolation_utils", "common.sim2", "common.bevparams", "models.early_fusion",
-                 "models.resnet_factory", "train_utils", "training_config"):
+                 "models.resnet_factory", "train_utils", "training_config", "dataset", "dataset.zind_data", "dataset.zind_partition",
+                 "utils.pr_utils"):
         sys.modules.setdefault(f"salve.{name}", importlib.import_module(f"salve_amd.{name}"))

@@ -1,0 +1,144 @@
+"""Inference drivers and the prediction wire format (scripts/test.py of the reference).
+
+* `save_edge_classifications_to_disk` -- one `batch_{i}.json` per batch with y_hat, y_true, y_hat_probs, fp0, fp1
+  (scripts/test.py:52-81); fp0 / fp1 are tile paths whose NAMES carry the hypothesis identity that
+  salve/common/edge_classification.py:145-175 parses back (building = parent directory, floor id, pano ids,
+  identity|rotated, W/D/O pair uuid), so the pose-graph stage consumes GPU results unchanged.
+* `run_test_epoch` / `evaluate_model` -- the un-fused path: tiles from disk (dataset/zind_data.py) through the verifier
+  (scripts/test.py:155-303), minus the matplotlib visualisation.
+* `run_fused_epoch` -- the MI355X path: hypotheses -> rasteriser -> verifier in HBM (pipeline.py), same prediction files,
+  no JPEG in between.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from salve_amd.utils import pr_utils
+
+
+class PrecisionRecallMeter:
+    """Running precision / recall / mean accuracy over batches (scripts/test.py:25-49)."""
+
+    def __init__(self) -> None:
+        self.all_y_true = np.zeros((0, 1))
+        self.all_y_hat = np.zeros((0, 1))
+
+    def update(self, y_true: np.ndarray, y_hat: np.ndarray) -> None:
+        self.all_y_true = np.vstack([self.all_y_true, np.asarray(y_true).reshape(-1, 1)])
+        self.all_y_hat = np.vstack([self.all_y_hat, np.asarray(y_hat).reshape(-1, 1)])
+
+    def get_metrics(self):
+        return pr_utils.compute_precision_recall(y_true=self.all_y_true, y_pred=self.all_y_hat)
+
+
+class ClassAccuracyMeter:
+    """Per-class accuracy and its mean: what the reference reads off SegmentationAverageMeter (avg_meter.py:35-110:
+    intersection / target counts per class, epsilon 1e-10)."""
+
+    def __init__(self, num_classes: int) -> None:
+        self.correct = np.zeros(num_classes)
+        self.total = np.zeros(num_classes)
+
+    def update(self, pred: np.ndarray, target: np.ndarray) -> None:
+        pred, target = np.asarray(pred).reshape(-1), np.asarray(target).reshape(-1)
+        for c in range(len(self.total)):
+            self.total[c] += (target == c).sum()
+            self.correct[c] += np.logical_and(target == c, pred == c).sum()
+
+    def get_metrics(self):
+        accs = self.correct / (self.total + 1e-10)
+        return accs, float(np.mean(accs))
+
+
+def save_edge_classifications_to_disk(serialization_save_dir: str, batch_idx: int, y_hat: torch.Tensor, y_true: torch.Tensor,
+                                      probs: torch.Tensor, fp0: Sequence[str], fp1: Sequence[str]) -> None:
+    """scripts/test.py:52-81: `y_hat_probs` is the probability of the PREDICTED class; JSON with indent 4
+    (salve/utils/io.py:24-36)."""
+    n = y_hat.shape[0]
+    save_dict = {
+        "y_hat": y_hat.cpu().numpy().tolist(),
+        "y_true": y_true.cpu().numpy().tolist(),
+        "y_hat_probs": probs[torch.arange(n, device=probs.device), y_hat].cpu().numpy().tolist(),
+        "fp0": list(fp0),
+        "fp1": list(fp1),
+    }
+    os.makedirs(serialization_save_dir, exist_ok=True)
+    with open(f"{serialization_save_dir}/batch_{batch_idx}.json", "w") as f:
+        json.dump(save_dict, f, indent=4)
+
+
+def _summary(split: str, ckpt_fpath: str, cls: ClassAccuracyMeter, pr: PrecisionRecallMeter) -> Dict[str, Any]:
+    accs, avg = cls.get_metrics()
+    prec, rec, macc = pr.get_metrics()
+    return {"split": split, "checkpoint_file_path": ckpt_fpath, "average_accuracy": avg, "class_accuracies": accs.tolist(),
+            "precision": prec, "recall": rec, "mean_accuracy": macc}
+
+
+@torch.no_grad()
+def run_test_epoch(args, serialization_save_dir: str, ckpt_fpath: str, model, data_loader, split: str, save_viz: bool = False,
+                   serialize_predictions: bool = True) -> Dict[str, Any]:
+    """scripts/test.py:155-277.  Batches are (x1, x2[, x3, x4[, x5, x6]], is_match, fp0, fp1)."""
+    from salve_amd import train_utils
+
+    if save_viz:
+        raise RuntimeError("false-positive visualisation (matplotlib) is outside the accelerated path")
+    cls, pr = ClassAccuracyMeter(args.num_ce_classes), PrecisionRecallMeter()
+    for i, example in enumerate(data_loader):
+        *xs, is_match, fp0, fp1 = example
+        xs = list(xs) + [None] * (6 - len(xs))
+        dev = xs[0].device if not torch.cuda.is_available() else torch.device("cuda")
+        xs = [x.to(dev, non_blocking=True) if x is not None else None for x in xs]
+        gt = torch.as_tensor(is_match).to(dev)
+        probs, _ = train_utils.cross_entropy_forward(model, split, *xs, gt)
+        y_hat = torch.argmax(probs, dim=1)
+        cls.update(y_hat.cpu().numpy(), gt.reshape(-1).cpu().numpy())
+        pr.update(y_true=gt.reshape(-1).cpu().numpy(), y_hat=y_hat.cpu().numpy())
+        if serialize_predictions:
+            save_edge_classifications_to_disk(serialization_save_dir, i, y_hat, gt.reshape(-1), probs, fp0, fp1)
+    return _summary(split, ckpt_fpath, cls, pr)
+
+
+def evaluate_model(serialization_save_dir: str, ckpt_fpath: str, args, split: str, save_viz: bool = False) -> Dict[str, Any]:
+    """scripts/test.py:280-303: data loader -> model -> checkpoint -> run_test_epoch -> `{ckpt stem}.json` summary."""
+    from salve_amd import train_utils
+
+    loader = train_utils.get_dataloader(args, split=split)
+    model = train_utils.load_model_checkpoint(ckpt_fpath, train_utils.get_model(args), args)
+    metrics = run_test_epoch(args, serialization_save_dir, ckpt_fpath, model.eval(), loader, split, save_viz)
+    with open(f"{Path(ckpt_fpath).stem}.json", "w") as f:
+        json.dump(metrics, f, indent=4)
+    return metrics
+
+
+@torch.no_grad()
+def run_fused_epoch(pipe, hypotheses, tile_names: Sequence[Sequence[str]], y_true: Optional[np.ndarray], serialization_save_dir: str,
+                    batch_size: int = 64, ckpt_fpath: str = "", split: str = "test", world: int = 1, rank: int = 0) -> Dict[str, Any]:
+    """Render + verify a hypothesis table on the GPU (pipeline.RenderVerifyPipeline) and write the SAME prediction
+    files as run_test_epoch.  `tile_names[j]` = (fp0, fp1): the floor-tile paths the un-fused path would have written
+    for hypothesis j (utils/bev_rendering_utils.bev_fname_from_img_fpath under `{root}/{label}/{building}/`); they are
+    only used as names.  y_true: [N] labels (0 / 1) or None (then 0).  With world > 1 every rank scores its contiguous
+    shard (the table passed in must already be the shard) and rank 0 writes the files after the all-gather of logits."""
+    from salve_amd.pipeline import gather_logits
+
+    prepared = pipe.prepare(hypotheses)
+    logits = gather_logits(pipe.score(prepared), world)
+    probs = torch.softmax(logits, dim=1)  # train_utils.py:31
+    y_hat = torch.argmax(probs, dim=1)
+    n = int(probs.shape[0])
+    gt = torch.zeros(n, dtype=torch.long, device=probs.device) if y_true is None else torch.as_tensor(np.asarray(y_true), device=probs.device).long()
+    cls, pr = ClassAccuracyMeter(int(probs.shape[1])), PrecisionRecallMeter()
+    cls.update(y_hat.cpu().numpy(), gt.cpu().numpy())
+    pr.update(y_true=gt.cpu().numpy(), y_hat=y_hat.cpu().numpy())
+    if rank == 0:
+        for b, lo in enumerate(range(0, n, batch_size)):
+            hi = min(lo + batch_size, n)
+            save_edge_classifications_to_disk(serialization_save_dir, b, y_hat[lo:hi], gt[lo:hi], probs[lo:hi],
+                                              [tile_names[j][0] for j in range(lo, hi)], [tile_names[j][1] for j in range(lo, hi)])
+    return _summary(split, ckpt_fpath, cls, pr)

@@ -1,8 +1,9 @@
-"""Model build / checkpoint load / forward helpers with the reference's names.
+"""Model build / checkpoint load / forward / data-loading helpers with the reference's names.
 
 Mirror of the inference-side functions of salve/train_utils.py: get_model (:205-217), load_model_checkpoint
-(:229-242), cross_entropy_forward (:18-41).  Training-only helpers (optimiser, augmentation, LR schedule) are out of
-scope of the accelerated path.
+(:229-242), cross_entropy_forward (:18-41), get_val_test_transform (:126-159), get_img_transform_list (:162-170),
+get_dataloader (:183-203).  Training-only helpers (optimiser, augmentation, LR schedule) are out of scope of the
+accelerated path.
 """
 
 from __future__ import annotations
@@ -47,3 +48,31 @@ def cross_entropy_forward(model: nn.Module, split: str, x1: Tensor, x2: Tensor, 
         probs = torch.nn.functional.softmax(logits.clone(), dim=1)
         loss = torch.nn.functional.cross_entropy(logits, is_match.squeeze())
     return probs, loss
+
+
+def get_val_test_transform(args: TrainingConfig):
+    """Resize(resize_h, resize_w) -> centre Crop(train_h, train_w) -> ToTensor -> Normalize(ImageNet), for 1, 2 or 3
+    modalities (2 / 4 / 6 images per example): salve/train_utils.py:126-159.  Runs on the GPU (transforms.py)."""
+    from salve_amd.transforms import ValTestTransform
+
+    if len(args.modalities) not in (1, 2, 3):
+        raise RuntimeError(f"Unsupported modalities. {str(args.modalities)}")
+    return ValTestTransform((args.resize_h, args.resize_w), (args.train_h, args.train_w))
+
+
+def get_img_transform_list(args: TrainingConfig, split: str):
+    if split == "train":
+        raise RuntimeError("training augmentation is outside the accelerated path")
+    if split not in ("val", "test"):
+        raise RuntimeError(f"unknown split {split}")
+    return get_val_test_transform(args)
+
+
+def get_dataloader(args: TrainingConfig, split: str) -> torch.utils.data.DataLoader:
+    """DataLoader over the rendered tiles of a split (salve/train_utils.py:183-203): no shuffling, no dropped batch for
+    val / test.  The transform launches GPU kernels, so tiles are decoded in the calling process (num_workers = 0)
+    instead of in `args.workers` forked workers."""
+    from salve_amd.dataset.zind_data import ZindData
+
+    data = ZindData(split=split, transform=get_img_transform_list(args, split), args=args)
+    return torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=False, num_workers=0, drop_last=False)

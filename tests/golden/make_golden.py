@@ -222,5 +222,20 @@ def main():
         print(f.name, f.stat().st_size)
 
 
+def make_zind_partition() -> None:
+    """The official ZInD train/val/test building split (public data, https://github.com/zillow/zind zind_partition.json)
+    as the reference carries it (salve/dataset/zind_partition.py) -> salve_amd/dataset/zind_partition.json.
+    The four rendering JPEGs under tests/golden/renderings/ and the two a_Sim2_b*.json files are the reference's own test
+    fixtures (tests/test_data/Renderings/..., tests/test_data/a_Sim2_b*.json), copied byte for byte."""
+    import json
+
+    from salve.dataset.zind_partition import DATASET_SPLITS
+
+    out = Path(__file__).resolve().parents[2] / "salve_amd" / "dataset" / "zind_partition.json"
+    with open(out, "w") as f:
+        json.dump(DATASET_SPLITS, f, separators=(",", ":"))
+
+
 if __name__ == "__main__":
     main()
+    make_zind_partition()
