@@ -138,6 +138,14 @@ int salve_remove_hallucinated(const uint8_t* sparse, const uint8_t* interp, int3
 int salve_bev_keys_from_pixels(const salve_bev_config_t* cfg, const int32_t* xy, const uint8_t* rgb, int32_t n_points, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Panorama ingest: n RGB uint8 images [n, src_h, src_w, 3] -> [n, dst_h, dst_w, 3] with the arithmetic of
+ * cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_LINEAR), the call every panorama goes through before
+ * back-projection (salve/utils/bev_rendering_utils.py:370-375: 2048x1024 JPEG -> 1024x512).  An exact 2x down-scale
+ * takes OpenCV's INTER_AREA fast path, (a + b + c + d + 2) >> 2, and needs no tables; any other size uses the 11-bit
+ * fixed-point taps coef_y [dst_h, 4], coef_x [dst_w, 4] = {src0, src1, w0, w1} (same layout as salve_bev_tiles). */
+int salve_resize_rgb_u8(const uint8_t* src, int32_t n, int32_t src_h, int32_t src_w, uint8_t* dst, int32_t dst_h, int32_t dst_w,
+                        const int32_t* coef_y, const int32_t* coef_x, void* stream);
+
 /* BEV uint32 -> uint8 [n, bev_h, bev_w, 3], the array render_bev_image returns (bev_rendering_utils.py:328). */
 int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream);
 

@@ -458,6 +458,22 @@ def resize_linear_u8(img: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
+def resize_pano_u8(img: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
+    """cv2.resize(rgb, (w, h), interpolation=cv2.INTER_LINEAR) as applied to every panorama at
+    salve/utils/bev_rendering_utils.py:370-375 (2048x1024 -> 1024x512).  OpenCV's resize() replaces INTER_LINEAR by its
+    INTER_AREA fast path when both scale factors are exactly 2 (imgproc/src/resize.cpp: "in case of scale_x && scale_y
+    is equal to 2, INTER_AREA (fast) also is equal to INTER_LINEAR"): the rounded 2x2 box mean (a+b+c+d+2)>>2.
+    cv2 is not importable here: parity with OpenCV itself is unpinned; sizes already equal are returned unchanged."""
+    h, w = out_hw
+    H, W = img.shape[:2]
+    if (H, W) == (h, w):
+        return img
+    if H == 2 * h and W == 2 * w:
+        a = img.astype(np.int64)
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    return resize_linear_u8(img, out_hw)
+
+
 def imagenet_mean_std():
     """salve/utils/normalization_utils.py:13-26 (values on the 0-255 scale)."""
     mean = [item * 255 for item in [0.485, 0.456, 0.406]]

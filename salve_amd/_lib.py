@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "salve_bev_keys_from_pixels",
     "salve_bev_export_u8",
     "salve_bev_tiles",
+    "salve_resize_rgb_u8",
     "salve_resnet_create",
     "salve_resnet_destroy",
     "salve_resnet_workspace_bytes",
@@ -104,6 +105,8 @@ def load() -> ctypes.CDLL:
     lib.salve_bev_export_u8.restype = ctypes.c_int
     lib.salve_bev_tiles.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
     lib.salve_bev_tiles.restype = ctypes.c_int
+    lib.salve_resize_rgb_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp]
+    lib.salve_resize_rgb_u8.restype = ctypes.c_int
     lib.salve_resnet_create.argtypes = [i32, i32, vp, i32, vp, sz, vp, sz, vp, sz]
     lib.salve_resnet_create.restype = vp
     lib.salve_resnet_destroy.argtypes = [vp]

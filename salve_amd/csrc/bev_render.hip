@@ -596,6 +596,40 @@ __global__ __launch_bounds__(256) void bev_export_kernel(const uint32_t* __restr
     out[3 * i + 2] = (uint8_t)(v >> 16);
 }
 
+// Panorama ingest: cv2.resize(rgb, (w, h), INTER_LINEAR) on uint8 RGB (bev_rendering_utils.py:370-375).  OpenCV turns an
+// exact 2x down-scale into its INTER_AREA fast path ((a + b + c + d + 2) >> 2); everything else is the 11-bit fixed-point
+// bilinear of the tile kernel above.  One thread per destination pixel.
+__global__ __launch_bounds__(256) void resize_rgb_kernel(const uint8_t* __restrict__ src, int n, int Hs, int Ws,
+                                                         uint8_t* __restrict__ dst, int Hd, int Wd,
+                                                         const int32_t* __restrict__ coef_y, const int32_t* __restrict__ coef_x,
+                                                         int area2) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * Hd * Wd) return;
+    const int x = (int)(i % Wd), y = (int)((i / Wd) % Hd);
+    const uint8_t* img = src + (i / ((size_t)Hd * Wd)) * (size_t)Hs * Ws * 3;
+    uint8_t* o = dst + i * 3;
+    if (area2) {
+        const uint8_t* r0 = img + ((size_t)(2 * y) * Ws + 2 * x) * 3;
+        const uint8_t* r1 = r0 + (size_t)Ws * 3;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) o[ch] = (uint8_t)((r0[ch] + r0[3 + ch] + r1[ch] + r1[3 + ch] + 2) >> 2);
+        return;
+    }
+    const int4 cy = reinterpret_cast<const int4*>(coef_y)[y];
+    const int4 cx = reinterpret_cast<const int4*>(coef_x)[x];
+    const uint8_t* p00 = img + ((size_t)cy.x * Ws + cx.x) * 3;
+    const uint8_t* p01 = img + ((size_t)cy.x * Ws + cx.y) * 3;
+    const uint8_t* p10 = img + ((size_t)cy.y * Ws + cx.x) * 3;
+    const uint8_t* p11 = img + ((size_t)cy.y * Ws + cx.y) * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const int S0 = p00[ch] * cx.z + p01[ch] * cx.w;  // horizontal pass, x2048
+        const int S1 = p10[ch] * cx.z + p11[ch] * cx.w;
+        const int r = (((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2;
+        o[ch] = (uint8_t)min(max(r, 0), 255);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ stand-alone utilities
 // zorder_utils.choose_elevated_repeated_vals (zorder_utils.py:10-83) for arbitrary slice planes.
 __global__ __launch_bounds__(256) void zorder_splat_kernel(const int32_t* __restrict__ x, const int32_t* __restrict__ y,
@@ -884,6 +918,22 @@ int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t b
     if (!bev || !out || n < 0 || bev_h <= 0 || bev_w <= 0) { salve_fail("salve_bev_export_u8: bad argument"); return SALVE_ERR_BAD_ARG; }
     const size_t npx = (size_t)n * bev_h * bev_w;
     hipLaunchKernelGGL(bev_export_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bev, npx, out);
+    SALVE_HIP_CHECK(hipGetLastError());
+    return SALVE_OK;
+}
+
+int salve_resize_rgb_u8(const uint8_t* src, int32_t n, int32_t src_h, int32_t src_w, uint8_t* dst, int32_t dst_h, int32_t dst_w,
+                        const int32_t* coef_y, const int32_t* coef_x, void* stream) {
+    if (n == 0) return SALVE_OK;
+    if (!src || !dst || n < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) {
+        salve_fail("salve_resize_rgb_u8: null pointer or bad size");
+        return SALVE_ERR_BAD_ARG;
+    }
+    const int area2 = (src_h == 2 * dst_h && src_w == 2 * dst_w) ? 1 : 0;
+    if (!area2 && (!coef_y || !coef_x)) { salve_fail("salve_resize_rgb_u8: tap tables are required unless the scale is exactly 2"); return SALVE_ERR_BAD_ARG; }
+    const size_t total = (size_t)n * dst_h * dst_w;
+    hipLaunchKernelGGL(resize_rgb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, n, src_h, src_w, dst,
+                       dst_h, dst_w, coef_y, coef_x, area2);
     SALVE_HIP_CHECK(hipGetLastError());
     return SALVE_OK;
 }

@@ -68,8 +68,14 @@ class RenderVerifyPipeline:
     # ------------------------------------------------------------------ panoramas
     def load_panos(self, rgb: np.ndarray, depth: np.ndarray) -> None:
         """Upload P panoramas and render their hypothesis-independent (identity) BEV images once."""
-        self.pano_rgb, self.pano_depth = self.ras.upload_panos(rgb, depth)
-        P = self.n_panos = int(rgb.shape[0])
+        self.set_panos(*self.ras.upload_panos(rgb, depth))
+
+    def set_panos(self, rgb_dev: torch.Tensor, depth_dev: torch.Tensor) -> None:
+        """Panoramas already on the device (ingest.PanoStore): uint8 [P,H,W,3], uint16 bits as int16 [P,H,W]."""
+        if tuple(rgb_dev.shape[1:3]) != tuple(self.ras.pano_hw) or tuple(depth_dev.shape[1:]) != tuple(self.ras.pano_hw):
+            raise RuntimeError(f"panoramas must be {self.ras.pano_hw}, got {tuple(rgb_dev.shape[1:3])} / {tuple(depth_dev.shape[1:])}")
+        self.pano_rgb, self.pano_depth = rgb_dev.contiguous(), depth_dev.contiguous()
+        P = self.n_panos = int(rgb_dev.shape[0])
         S = len(self.surfaces)
         idx = np.repeat(np.arange(P), S)
         surf = np.tile([SURFACES[s] for s in self.surfaces], P)

@@ -1,0 +1,111 @@
+"""SURVEY section 8f row 3 on the GPU: the panorama resize kernel against the oracle's restatement of cv2.resize, the
+device-resident pano store against the host loader, and disk -> predictions for a floor through the fused pipeline
+against the un-fused path (tiles written to disk, read back, verified)."""
+
+import json
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import bev_oracle as bo  # noqa: E402
+from salve_amd import evaluate, ingest, synthetic  # noqa: E402
+from salve_amd.common.sim2 import Sim2  # noqa: E402
+from salve_amd.utils import image_io  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("src_hw,dst_hw", [((1024, 2048), (512, 1024)), ((500, 1000), (512, 1024)), ((768, 1536), (512, 1024)),
+                                           ((64, 128), (32, 64)), ((512, 1024), (512, 1024))])
+def test_pano_resize_kernel_matches_oracle(src_hw, dst_hw):
+    rng = np.random.default_rng(src_hw[0])
+    img = rng.integers(0, 256, size=(2, *src_hw, 3), dtype=np.uint8)
+    got = ingest.resize_rgb_on_device(torch.from_numpy(img).to(DEV), dst_hw).cpu().numpy()
+    for k in range(2):
+        assert np.array_equal(got[k], bo.resize_pano_u8(img[k], dst_hw))
+
+
+def make_floor(tmp_path, n_panos=4, n_hyp=6):
+    """A synthetic building on disk in the reference's layout: 2048x1024 JPEG panoramas, 1024x512 .depth.png maps,
+    Sim(2) hypothesis files."""
+    raw, depth_root, hyp_root = tmp_path / "zind", tmp_path / "depth", tmp_path / "hyp"
+    (raw / "0003" / "panos").mkdir(parents=True)
+    fpaths = {}
+    for i in range(n_panos):
+        rgb, depth = synthetic.make_pano(i)
+        big = np.repeat(np.repeat(rgb, 2, axis=0), 2, axis=1)            # 2048 x 1024
+        fp = raw / "0003" / "panos" / f"floor_01_partial_room_{i:02d}_pano_{i + 3}.jpg"
+        image_io.write_jpeg(str(fp), big)
+        image_io.write_depth_png(str(depth_root / "0003" / f"{fp.stem}.depth.png"), depth)
+        fpaths[i + 3] = str(fp)
+    hyp = synthetic.make_hypotheses(n_hyp, n_panos, seed=2)
+    for j in range(n_hyp):
+        label = "gt_alignment_approx" if j % 3 == 0 else "incorrect_alignment"
+        d = hyp_root / "0003" / "floor_01" / label
+        d.mkdir(parents=True, exist_ok=True)
+        Sim2(hyp.R[j].astype(np.float64), hyp.t[j].astype(np.float64), 1.0).save_as_json(
+            str(d / f"{int(hyp.i1[j]) + 3}_{int(hyp.i2[j]) + 3}__door_{j}_0_{'identity' if j % 2 else 'rotated'}.json"))
+    return raw, depth_root, hyp_root, fpaths
+
+
+def test_pano_store_equals_host_loader(tmp_path):
+    raw, depth_root, _, fpaths = make_floor(tmp_path)
+    store = ingest.PanoStore(DEV).load(ingest.floor_pano_fpaths(str(raw), "0003"), str(depth_root), "0003", [3, 4, 5, 6])
+    assert len(store) == 4 and store.rgb.shape == (4, 512, 1024, 3) and store.depth.shape == (4, 512, 1024)
+    for pid, k in store.index.items():
+        rgb = bo.resize_pano_u8(image_io.read_rgb(fpaths[pid]), (512, 1024))
+        assert np.array_equal(store.rgb[k].cpu().numpy(), rgb)
+        assert np.array_equal(store.depth[k].cpu().numpy().view(np.uint16), image_io.read_depth_png(str(depth_root / "0003" / f"{Path(fpaths[pid]).stem}.depth.png")))
+    with pytest.raises((ValueError, FileNotFoundError)):
+        ingest.PanoStore(DEV).load({3: fpaths[3]}, str(tmp_path / "nowhere"), "0003", [3])
+
+
+def test_score_floor_fused_equals_unfused(tmp_path):
+    """Same floor, two routes: (a) disk -> device -> render -> verify -> batch files; (b) the reference's two scripts'
+    route: render tiles to JPEG, read them back through the dataset, verify.  JPEG is lossy, so (b)'s tiles differ from
+    (a)'s by compression noise: predictions are compared loosely, names and labels exactly."""
+    from salve_amd.dataset.zind_data import ZindData
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from salve_amd.utils import bev_rendering_utils as bru
+    from salve_amd import train_utils
+    from tests.test_gpu_dataset import config
+
+    raw, depth_root, hyp_root, fpaths = make_floor(tmp_path)
+    torch.manual_seed(3)
+    model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    m = ingest.score_floor(model, torch.device(DEV), str(raw), str(depth_root), str(hyp_root), str(tmp_path / "bev"), "0003", "floor_01",
+                           str(tmp_path / "preds_fused"), batch_size=4, chunk=4)
+    files = sorted((tmp_path / "preds_fused").glob("batch_*.json"))
+    assert [f.name for f in files] == ["batch_0.json", "batch_1.json"]
+    fused = [json.load(open(f)) for f in files]
+    hyps = ingest.load_floor_hypotheses(str(hyp_root), "0003", "floor_01")
+    assert sum((g["y_true"] for g in fused), []) == hyps.label.tolist() == [1, 1, 0, 0, 0, 0]
+    assert 0 <= m["precision"] <= 1
+
+    # (b) un-fused: write the floor tiles exactly as scripts/render_dataset_bev.py would
+    img_fpaths = ingest.floor_pano_fpaths(str(raw), "0003")
+    for j in range(len(hyps)):
+        label = "gt_alignment_approx" if hyps.label[j] else "incorrect_alignment"
+        for surface in ("floor", "ceiling"):
+            bru.generate_texture_maps_for_pair(img_fpaths, surface, hyps.fpaths[j], int(hyps.pair_idx[j]), label, str(tmp_path / "bev"), "0003",
+                                               "floor_01", str(depth_root), ["rgb_texture"], None, None)
+    names = hyps.tile_names(str(tmp_path / "bev"), img_fpaths)
+    written = {n for pair in names for n in pair if Path(n).exists()}
+    assert sum((g["fp0"] for g in fused), []) == [n[0] for n in names]
+    fused_by_name = {}
+    for g in fused:
+        for k in range(len(g["y_hat"])):
+            fused_by_name[g["fp0"][k]] = (g["y_hat"][k], g["y_hat_probs"][k])
+    # read back the pairs whose two floor tiles exist (a render with no point in the window writes nothing)
+    for a, b in names:
+        if a in written and b in written:
+            x = train_utils.get_val_test_transform(config("", ["floor_rgb_texture"]))(image_io.read_rgb(a), image_io.read_rgb(b))
+            with torch.no_grad():
+                probs = torch.softmax(model.cuda()(x[0][None], x[1][None], None, None, None, None), 1)[0]
+            y, p = fused_by_name[a]
+            assert abs(float(probs[y]) - p) < 0.1
