@@ -70,7 +70,7 @@ struct DevCfg {
 __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
     DevCfg c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, const double* __restrict__ sphere,
     const salve_bev_hyp_t* __restrict__ hyps, uint32_t* __restrict__ keys, const uint8_t** __restrict__ colour_src,
-    int16_t* __restrict__ dbg_xy, int32_t* __restrict__ in_window) {
+    int16_t* __restrict__ dbg_xy, int32_t* __restrict__ in_window, int pass) {
     const int rid = blockIdx.y;
     const salve_bev_hyp_t h = hyps[rid];
     // where the densify kernel finds the colour of point index i of this render: colour_src[rid] + 3 i
@@ -120,14 +120,20 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
                 const double fy = rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
                 ix = (int)fx;
                 iy = (int)fy;
-                if (in_window) atomicAdd(in_window + rid, 1);
+                if (in_window && pass == 0) atomicAdd(in_window + rid, 1);
                 const double zs = floor(z) - c.zmin;  // unit slices from an integer z_min: exact
                 if (zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H) {
-                    atomicMax(kimg + (size_t)iy * c.W + ix, ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | (uint32_t)(p0 + k));
+                    const uint32_t key = ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | (uint32_t)(p0 + k);
+                    uint32_t* cell = kimg + (size_t)iy * c.W + ix;
+                    if (pass == 0) {
+                        *cell = key;                                  // racy plain store: SOME contender of the pixel lands
+                    } else if (key > *cell) {
+                        atomicMax(cell, key);                         // rare: only contenders above what landed
+                    }
                 }
             }
         }
-        if (dbg_xy) {
+        if (dbg_xy && pass == 0) {
             int16_t* o = dbg_xy + ((size_t)rid * c.npts + p0 + k) * 2;
             o[0] = (int16_t)ix;
             o[1] = (int16_t)iy;
@@ -795,9 +801,16 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         const int pts_per_block = SCATTER_THREADS * PTS_PER_THREAD;
         dim3 g1((d.npts + pts_per_block - 1) / pts_per_block, n);
         if (in_window) SALVE_HIP_CHECK(hipMemsetAsync(in_window, 0, (size_t)n * sizeof(int32_t), s));
-        hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, ws.keys,
-                           ws.colour_src, dbg_img_xy, in_window);
-        SALVE_HIP_CHECK(hipGetLastError());
+        // Two passes instead of one atomicMax per point (a device-scope atomic is a 64-byte request to the memory side;
+        // 52 k of them per render were 80 % of this stage): pass 0 stores keys with plain stores -- for a pixel with
+        // several contenders an arbitrary one lands --, pass 1 recomputes every point and raises the pixel with an
+        // atomicMax only where its key exceeds what landed.  Whatever landed is a contender, every larger contender
+        // then takes part in the atomic maximum: the result is the maximum over all contenders.
+        for (int pass = 0; pass < 2; pass++) {
+            hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, ws.keys,
+                               ws.colour_src, dbg_img_xy, in_window, pass);
+            SALVE_HIP_CHECK(hipGetLastError());
+        }
     }
     if (densify) {
         const int tab_status = ensure_star_table();
