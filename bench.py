@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 # HBM bytes of one bev_densify_kernel launch of 512 renders from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate
 # passes, KiB units; profiles/r01_pmc_traffic.md).  The kernel reads 4 B / lane, for which FETCH_SIZE is uncalibrated:
 # the read side is taken as counted (lower bound).
-DENSIFY_TRAFFIC_BYTES_512 = (610310 + 1053995) * 1024
+DENSIFY_TRAFFIC_BYTES_PER_RENDER = (610310 + 1053995) * 1024 / 512  # measured on launches of 512 renders; one workgroup per render
 
 
 def cpu_baseline(n_hyp: int, procs: int):
@@ -73,7 +73,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hyps", type=int, default=4096, help="hypotheses per GPU")
     ap.add_argument("--panos", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=512)
+    ap.add_argument("--chunk", type=int, default=1024, help="hypotheses per render / verify launch")
     ap.add_argument("--no-overlap", action="store_true", help="render and verify on one HIP stream")
     ap.add_argument("--layers", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,7 +148,7 @@ def main() -> None:
                        "cached_identity_renders": args.panos, "chunk": args.chunk, "parallelism": f"hypothesis-shard x{world}"},
             "roofline": {"kernel": "bev_densify_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": DENSIFY_TRAFFIC_BYTES_512 if renders == 512 else None,
+                         "traffic": int(DENSIFY_TRAFFIC_BYTES_PER_RENDER * renders),
                          "launch_ms": round(dens_ms, 3), "launches_timed": len(full), "renders_per_launch": renders, "algorithmic_bytes_per_render": BYTES_PER_RENDER},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -435,7 +435,9 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         if (wy1 > g.by1) wy1 = g.by1;
         if (wx1 > g.bx1) wx1 = g.bx1;
         sd_scan_rows<false>(g, edge, wy0, wy1, 1, wx0, wx1, &best);
+        SD_LAP(window, lap);
         sd_share_best(g, edge, &best, &shx, &shy);
+        SD_LAP(share, lap);
         if (best.px >= 0) break;
         if (wy0 <= g.by0 && wx0 <= g.bx0 && wy1 >= g.by1 && wx1 >= g.bx1) {
             SD_LAP(far, lap);
@@ -461,7 +463,9 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
             SD_COUNT(apex_slow);
             // one sweep over the circle's rows: what the window already covered is cut away by the circle, cheaply
             sd_scan_rows<true>(g, edge, cy0, cy1, 1, cx0, cx1, &best);
+            SD_LAP(slow, lap);
             sd_share_best(g, edge, &best, &shx, &shy);
+            SD_LAP(share, lap);
         }
         SD_LAP(slow, lap);
     }
@@ -496,7 +500,9 @@ SD_FN int sd_star(const SdGrid& g, int sx, int sy, Emit& emit) {
         return steps + 1;
     }
     int n0x, n0y;
+    long long lap_n = SD_NOW();
     if (!sd_nearest(g, sx, sy, &n0x, &n0y)) return 0;
+    SD_LAP(nearest, lap_n);
     int ax = n0x, ay = n0y;
     bool closed = false;
     for (;;) {  // counter-clockwise from the nearest neighbour
