@@ -58,7 +58,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // One LDS stage (load, barrier, multiply, barrier; <= 35 KB): four workgroups per CU hide each other's latency.  Measured
 // on every layer of ResNet-50 at batch 512, that beats two stages with the next tile's loads in flight under the MFMAs
 // (64 KB, two workgroups per CU) by 25-45 %: occupancy, not explicit pipelining, is what this tile size wants.
-template <int BN>
+// POINTWISE: 1x1 / stride 1 / pad 0 -- output pixel m reads input pixel m, so the im2col index arithmetic (three integer
+// divisions per staged row, bounds checks per k-tile) disappears; these are 32 of ResNet-50's 53 convolutions.
+template <int BN, bool POINTWISE>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p) {
     constexpr int WN = BN / 2;       // wave tile width
     constexpr int NT = WN / 16;      // 16-wide MFMA tiles per wave along n
@@ -87,15 +89,23 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     // per-thread im2col rows (fixed for the whole K loop)
     int iy0[4], ix0[4];
     long long boff[4];
+    const uint16_t* rowp[4];  // POINTWISE: the input pixel's channels (or the zero page, with stride 0)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int m = m0 + row_base + i * 32;
         const bool valid = m < p.M;
-        const int mm = valid ? m : 0;
-        const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-        iy0[i] = valid ? oy * p.stride - p.pad : -100000;  // rows beyond M read zeros
-        ix0[i] = ox * p.stride - p.pad;
-        boff[i] = (long long)b * p.Hi * p.Wi;
+        if (POINTWISE) {
+            rowp[i] = valid ? p.in + (long long)m * p.Cin + chunk * 8 : nullptr;
+            iy0[i] = ix0[i] = 0;
+            boff[i] = 0;
+        } else {
+            const int mm = valid ? m : 0;
+            const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+            iy0[i] = valid ? oy * p.stride - p.pad : -100000;  // rows beyond M read zeros
+            ix0[i] = ox * p.stride - p.pad;
+            boff[i] = (long long)b * p.Hi * p.Wi;
+            rowp[i] = nullptr;
+        }
     }
     const uint16_t* wrow = p.w + (long long)(n0 + row_base) * p.K + chunk * 8;
 
@@ -113,9 +123,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
         uint16_t* Bs_ = As_ + BM * BK;                                                                                 \
         const int dy_ = (int8_t)((E) & 0xFF), dx_ = (int8_t)(((E) >> 8) & 0xFF), coff_ = ((E) >> 16) & 0xFFFF;          \
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                \
-            const int iy = iy0[i] + dy_, ix = ix0[i] + dx_;                                                            \
-            const bool ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;                                              \
-            const uint16_t* src = ok ? p.in + ((boff[i] + (long long)iy * p.Wi + ix) * p.Cin + coff_) : p.zeros;       \
+            const uint16_t* src;                                                                                       \
+            if (POINTWISE) {                                                                                           \
+                src = rowp[i] ? rowp[i] + (KT) * BK : p.zeros;                                                         \
+            } else {                                                                                                   \
+                const int iy = iy0[i] + dy_, ix = ix0[i] + dx_;                                                        \
+                const bool ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;                                          \
+                src = ok ? p.in + ((boff[i] + (long long)iy * p.Wi + ix) * p.Cin + coff_) : p.zeros;                   \
+            }                                                                                                          \
             __builtin_amdgcn_global_load_lds((global_cptr)src, (lds_ptr)(As_ + i * 32 * BK), 16, 0, 0);                \
         }                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < B_LOADS; j++)                                                            \
@@ -123,13 +138,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
                                              (lds_ptr)(Bs_ + j * 32 * BK), 16, 0, 0);                                  \
     }
 
-    int32_t e_next = p.ktab[chunk];
+    int32_t e_next = POINTWISE ? 0 : p.ktab[chunk];
     const int frag_row = lane & 15, frag_q = lane >> 4, frag_sw = (frag_row >> 1) & 7;
     for (int kt = 0; kt < nkt; kt++) {
         ISSUE_TILE(kt, 0, e_next);
         {   // table entry of the next tile: a plain load, first used in the next iteration
             const int k1 = kt + 1 < nkt ? kt + 1 : nkt - 1;
-            e_next = p.ktab[k1 * 8 + chunk];
+            if (!POINTWISE) e_next = p.ktab[k1 * 8 + chunk];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the tile has landed
         __syncthreads();                                  // ... everyone's
@@ -411,10 +426,15 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             const int bn = (o.Cout % 128 == 0) ? 128 : 64;
             a.n_tiles = o.Cout / bn;
             const unsigned grid = (unsigned)(((a.m_tiles + 7) / 8) * 8 * a.n_tiles);
-            if (bn == 128) {
-                hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(grid), dim3(CONV_THREADS), 0, s, a);
+            const bool pointwise = o.KH == 1 && o.KW == 1 && o.stride == 1 && o.pad == 0;
+            if (bn == 128 && pointwise) {
+                hipLaunchKernelGGL((conv_igemm_kernel<128, true>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
+            } else if (bn == 128) {
+                hipLaunchKernelGGL((conv_igemm_kernel<128, false>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
+            } else if (pointwise) {
+                hipLaunchKernelGGL((conv_igemm_kernel<64, true>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
             } else {
-                hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(grid), dim3(CONV_THREADS), 0, s, a);
+                hipLaunchKernelGGL((conv_igemm_kernel<64, false>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
             }
         } else if (o.op == SALVE_OP_MAXPOOL) {
             const long long total = (long long)batch * o.Ho * o.Wo * (o.Cin / 8);
