@@ -75,6 +75,7 @@ def main() -> None:
     ap.add_argument("--panos", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=1024, help="hypotheses per render / verify launch")
     ap.add_argument("--no-overlap", action="store_true", help="render and verify on one HIP stream")
+    ap.add_argument("--streams", type=int, default=3, help="2: rasteriser | verifier; 3: scatter | densify | verifier")
     ap.add_argument("--layers", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -97,7 +98,7 @@ def main() -> None:
 
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(args.layers, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
-    pipe = RenderVerifyPipeline(model, dev, pano_hw=(PANO_H, PANO_W), chunk=args.chunk, overlap=not args.no_overlap)
+    pipe = RenderVerifyPipeline(model, dev, pano_hw=(PANO_H, PANO_W), chunk=args.chunk, overlap=not args.no_overlap, streams=args.streams)
     panos = [synthetic.make_pano(i, PANO_H, PANO_W) for i in range(args.panos)]
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     # weak scaling: every rank scores its own block of `hyps` hypotheses out of a table of world * hyps

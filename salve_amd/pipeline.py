@@ -43,7 +43,7 @@ def surfaces_for(modalities: Sequence[str]) -> List[str]:
 
 class RenderVerifyPipeline:
     def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: int = 512,
-                 overlap: bool = True) -> None:
+                 overlap: bool = True, streams: int = 3) -> None:
         self.device = torch.device(device)
         self.model = model
         self.surfaces = surfaces_for(model.modalities)
@@ -62,6 +62,9 @@ class RenderVerifyPipeline:
                                       device=self.device) for _ in range(self.nbuf)]
         self.bev, self.tiles = self.bevs[0], self.tile_bufs[0]
         self.render_stream = torch.cuda.Stream(self.device) if overlap else None
+        # streams = 3: the scatter of chunk i+2 (memory-side atomics, HBM) additionally runs under the densify of chunk
+        # i+1 (LDS / VALU) on a stream of its own, with two rasteriser workspaces
+        self.scatter_stream = torch.cuda.Stream(self.device) if (overlap and streams >= 3) else None
         self.pano_rgb = self.pano_depth = self.ref_bev = None
         self.n_panos = 0
 
@@ -115,11 +118,33 @@ class RenderVerifyPipeline:
             "jobs2": self.ras.upload_tile_jobs(st(jobs2_bev), st(jobs2_slot), st(jobs2_chan)),
         }
 
+    def _scatter_chunk(self, prepared, lo: int, n: int, slot: int) -> None:
+        S = len(self.surfaces)
+        self.ras.ws_slot = slot
+        self.ras.scatter(self.pano_rgb, self.pano_depth, prepared["rows"][lo * S * _lib.HYP_DTYPE.itemsize:], n * S)
+
+    def _densify_chunk(self, prepared, lo: int, n: int, buf: int, slot: int, timers=None) -> None:
+        S = len(self.surfaces)
+        jb = _lib.TILE_JOB_DTYPE.itemsize
+        bev, tiles = self.bevs[buf], self.tile_bufs[buf]
+        self.ras.ws_slot = slot
+        e0 = e1 = None
+        if timers is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.ras.densify(n * S, bev)
+        if timers is not None:
+            e1.record()
+            timers.append((e0, e1, n * S))
+        self.ras.tiles(bev, prepared["jobs1"][lo * S * jb:], n * S, tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
+        self.ras.tiles(self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
+
     def _render_chunk(self, prepared, lo: int, n: int, buf: int, timers=None) -> None:
         S = len(self.surfaces)
         hb, jb = _lib.HYP_DTYPE.itemsize, _lib.TILE_JOB_DTYPE.itemsize
         rows = prepared["rows"][lo * S * hb:]
         bev, tiles = self.bevs[buf], self.tile_bufs[buf]
+        self.ras.ws_slot = 0
         if timers is not None:  # benchmark: bracket the densify launch of this chunk with HIP events on its own stream
             self.ras.scatter(self.pano_rgb, self.pano_depth, rows, n * S)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -149,6 +174,30 @@ class RenderVerifyPipeline:
         self.render_stream.wait_stream(main)
         rendered = [torch.cuda.Event() for _ in chunks]
         consumed = [torch.cuda.Event() for _ in chunks]
+        if self.scatter_stream is not None:
+            self.scatter_stream.wait_stream(main)
+            scattered = [torch.cuda.Event() for _ in chunks]
+            densified = [torch.cuda.Event() for _ in chunks]
+            for i, (lo, n) in enumerate(chunks):
+                with torch.cuda.stream(self.scatter_stream):
+                    if i >= 2:
+                        self.scatter_stream.wait_event(densified[i - 2])  # that densify is done with this workspace
+                    self._scatter_chunk(prepared, lo, n, i % 2)
+                    scattered[i].record(self.scatter_stream)
+                with torch.cuda.stream(self.render_stream):
+                    self.render_stream.wait_event(scattered[i])
+                    if i >= self.nbuf:
+                        self.render_stream.wait_event(consumed[i - self.nbuf])  # the verifier is done with this buffer set
+                    self._densify_chunk(prepared, lo, n, i % self.nbuf, i % 2, timers)
+                    densified[i].record(self.render_stream)
+                main.wait_event(densified[i])
+                self.engine.forward_nhwc(self.tile_bufs[i % self.nbuf][:n], out=out[lo:lo + n])
+                consumed[i].record(main)
+            self.render_stream.wait_stream(main)
+            self.scatter_stream.wait_stream(self.render_stream)
+            main.wait_stream(self.scatter_stream)
+            self.ras.ws_slot = 0
+            return out
         for i, (lo, n) in enumerate(chunks):
             with torch.cuda.stream(self.render_stream):
                 if i >= self.nbuf:

@@ -112,7 +112,8 @@ class BevRasteriser:
         self.coef_y = torch.from_numpy(linear_resize_taps(resize, self.bev_hw[0])).to(self.device)
         self.coef_x = torch.from_numpy(linear_resize_taps(resize, self.bev_hw[1])).to(self.device)
         self.lut = torch.from_numpy(normalisation_lut()).to(self.device)
-        self._ws: Optional[torch.Tensor] = None
+        self._ws_slots = {}   # workspaces by slot: a caller that keeps two batches in flight alternates `ws_slot`
+        self.ws_slot = 0
 
     # ------------------------------------------------------------------ helpers
     def _stream(self) -> ctypes.c_void_p:
@@ -122,9 +123,10 @@ class BevRasteriser:
         need = self.lib.salve_bev_workspace_bytes(ctypes.byref(self.cfg), n)
         if need == 0:
             _lib.check(-1, "salve_bev_workspace_bytes")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        ws = self._ws_slots.get(self.ws_slot)
+        if ws is None or ws.numel() < need:
+            ws = self._ws_slots[self.ws_slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
     def upload_panos(self, rgb: np.ndarray, depth: np.ndarray) -> Tuple[torch.Tensor, torch.Tensor]:
         """rgb uint8 [P,H,W,3], depth uint16 [P,H,W] (host) -> device tensors (depth carried as int16 bits)."""

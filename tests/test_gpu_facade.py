@@ -105,7 +105,7 @@ def test_full_size_properties():
     panos = [synthetic.make_pano(i) for i in range(P)]
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
-    pipe = RenderVerifyPipeline(model, dev, chunk=64)  # two HIP streams (default)
+    pipe = RenderVerifyPipeline(model, dev, chunk=16)  # three HIP streams (default): scatter | densify | verify, 6 chunks
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     table = synthetic.make_hypotheses(N, P, seed=1)
     # identity pose through the posed branch == the cached identity render
@@ -113,7 +113,6 @@ def test_full_size_properties():
     table.t[0] = 0
     prep = pipe.prepare(table)
     a = pipe.score(prep).clone()
-    first_chunk_bev = pipe.bev[:32].clone()
     b = pipe.score(prep)
     torch.cuda.synchronize()
     assert torch.equal(a, b)  # deterministic
@@ -123,7 +122,10 @@ def test_full_size_properties():
     c = pipe2.score(pipe2.prepare(table))
     torch.cuda.synchronize()
     assert torch.equal(a, c)  # independent of the batching
-    pipe.score(pipe.prepare(table.shard(0, 3)))  # first 32 hypotheses land in bev[0:32]
+    pipe3 = RenderVerifyPipeline(model, dev, chunk=40, streams=2)  # two streams: rasteriser | verifier
+    pipe3.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
+    assert torch.equal(a, pipe3.score(pipe3.prepare(table)))
+    pipe.score(pipe.prepare(table.shard(0, 6)))  # the first 16 hypotheses: one chunk, lands in bev[0:16]
     torch.cuda.synchronize()
     assert torch.equal(pipe.bev[0], pipe.ref_bev[int(table.i1[0])])
     # two ranks' shards reproduce the single-rank logits
