@@ -38,6 +38,7 @@ struct SdLean {
     int sx, sy;
     int n0x, n0y, ax, ay;  // first neighbour, current edge end (relative to s)
     int dir, deg;
+    int round;             // table probe round of the current query (4 candidates per round)
     bool half;             // the walk started at the neighbour (+1, 0): stop at the first neighbour that precedes s in raster order
 };
 
@@ -46,6 +47,7 @@ SD_FN int sdl_lean_begin(SdLean& s, const SdGrid& g, int sx, int sy) {
     s.sy = sy;
     s.deg = 0;
     s.dir = 1;
+    s.round = 0;
     s.half = false;
     s.n0x = s.n0y = s.ax = s.ay = 0;
     if (g.tab == nullptr) return SDL_LEAN_HARD;
@@ -68,27 +70,31 @@ SD_FN int sdl_lean_begin(SdLean& s, const SdGrid& g, int sx, int sy) {
 
 template <class Emit>
 SD_FN int sdl_lean_step(SdLean& s, const SdGrid& g, Emit& emit) {
-    // Table probe: four entries per table read, four independent bitmap probes.  The right of s -> a is the left of
-    // a -> s: clockwise queries enter the table with the edge reversed.
+    // One round of the table probe per call: four entries per table read, four independent bitmap probes.  A query whose
+    // first four candidates are all empty (rare where the image is densely covered) simply takes another call, so lanes
+    // never wait for each other inside a probe loop.  The right of s -> a is the left of a -> s: clockwise queries enter the
+    // table with the edge reversed.
     const int ox = s.dir > 0 ? 0 : s.ax, oy = s.dir > 0 ? 0 : s.ay;
     const int vx = s.dir > 0 ? s.ax : -s.ax, vy = s.dir > 0 ? s.ay : -s.ay;
     int px = SDL_NONE, py = 0;
     if (vx >= -SDT_AMAX && vx <= SDT_AMAX && vy >= -SDT_AMAX && vy <= SDT_AMAX) {
         const uint32_t* row = (const uint32_t*)(g.tab + sdt_index(vx, vy) * (SDT_LEN * 2));
         const int bx = s.sx + ox, by = s.sy + oy;
-        for (int k = 0; k < SDT_LEN / 4; k++) {
-            const uint32_t e0 = row[2 * k], e1 = row[2 * k + 1];
-            const int x0 = (int8_t)(e0 & 0xFF), y0 = (int8_t)((e0 >> 8) & 0xFF), x1 = (int8_t)((e0 >> 16) & 0xFF), y1 = (int8_t)(e0 >> 24);
-            const int x2 = (int8_t)(e1 & 0xFF), y2 = (int8_t)((e1 >> 8) & 0xFF), x3 = (int8_t)((e1 >> 16) & 0xFF), y3 = (int8_t)(e1 >> 24);
-            const bool b0 = sdl_bit(g, bx + x0, by + y0), b1 = sdl_bit(g, bx + x1, by + y1);
-            const bool b2 = sdl_bit(g, bx + x2, by + y2), b3 = sdl_bit(g, bx + x3, by + y3);
-            if (b0 | b1 | b2 | b3) {
-                px = ox + (b0 ? x0 : b1 ? x1 : b2 ? x2 : x3);
-                py = oy + (b0 ? y0 : b1 ? y1 : b2 ? y2 : y3);
-                break;
-            }
+        const int k = s.round;
+        const uint32_t e0 = row[2 * k], e1 = row[2 * k + 1];
+        const int x0 = (int8_t)(e0 & 0xFF), y0 = (int8_t)((e0 >> 8) & 0xFF), x1 = (int8_t)((e0 >> 16) & 0xFF), y1 = (int8_t)(e0 >> 24);
+        const int x2 = (int8_t)(e1 & 0xFF), y2 = (int8_t)((e1 >> 8) & 0xFF), x3 = (int8_t)((e1 >> 16) & 0xFF), y3 = (int8_t)(e1 >> 24);
+        const bool b0 = sdl_bit(g, bx + x0, by + y0), b1 = sdl_bit(g, bx + x1, by + y1);
+        const bool b2 = sdl_bit(g, bx + x2, by + y2), b3 = sdl_bit(g, bx + x3, by + y3);
+        if (b0 | b1 | b2 | b3) {
+            px = ox + (b0 ? x0 : b1 ? x1 : b2 ? x2 : x3);
+            py = oy + (b0 ? y0 : b1 ? y1 : b2 ? y2 : y3);
+        } else if (k + 1 < SDT_LEN / 4) {
+            s.round = k + 1;  // same query, next four candidates
+            return SDL_LEAN_CONTINUE;
         }
     }
+    s.round = 0;
     if (px == SDL_NONE) {
         if (!sd_side_is_empty(g, s.sx, s.sy, s.sx + s.ax, s.sy + s.ay, s.dir)) return SDL_LEAN_HARD;
         // Hull edge.  A half walk owns nothing beyond it; a full walk goes back to its first neighbour and fans out
@@ -110,4 +116,3 @@ SD_FN int sdl_lean_step(SdLean& s, const SdGrid& g, Emit& emit) {
     if (++s.deg > 64) return SDL_LEAN_HARD;
     return SDL_LEAN_CONTINUE;
 }
-
