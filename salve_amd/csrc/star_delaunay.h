@@ -44,7 +44,7 @@ struct SdGrid {
 #define SDT_AMAX 5                                   // edge vectors with |ax|, |ay| <= SDT_AMAX
 #define SDT_SIDE (2 * SDT_AMAX + 1)
 #define SDT_NVEC (SDT_SIDE * SDT_SIDE)
-#define SDT_LEN 32                                   // candidates kept per vector
+#define SDT_LEN 64                                   // candidates kept per vector (measured: 32 -> 64 removes 13 % of the hard sites, 128 adds nothing)
 #define SDT_REACH 48                                 // search radius when building (must dwarf the kept candidates)
 
 struct SdTable {
@@ -393,11 +393,13 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
             const int8_t* row = g.tab + sdt_index(vx, vy) * (SDT_LEN * 2);
             int hit = -1;
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (g.nlanes == 64) {  // one candidate per lane, the lowest occupied entry wins
-                const int k = g.lane & (SDT_LEN - 1);
-                const bool b = g.lane < SDT_LEN && sd_occupied(g, ox + row[2 * k], oy + row[2 * k + 1]);
-                const unsigned long long m = __ballot(b);
-                if (m) hit = (int)__ffsll((long long)m) - 1;
+            if (g.nlanes == 64) {  // one candidate per lane and round, the lowest occupied entry wins
+                for (int k0 = 0; k0 < SDT_LEN && hit < 0; k0 += 64) {
+                    const int k = k0 + g.lane;
+                    const bool b = k < SDT_LEN && sd_occupied(g, ox + row[2 * (k & (SDT_LEN - 1))], oy + row[2 * (k & (SDT_LEN - 1)) + 1]);
+                    const unsigned long long m = __ballot(b);
+                    if (m) hit = k0 + (int)__ffsll((long long)m) - 1;
+                }
             } else
 #endif
             {
