@@ -31,7 +31,7 @@ for rep in range(6):
     print(mode, "rep", rep, "renders differing:", d)
 if mode.startswith("resnet"):
     pass
-if mode in ("resnet", "resnet_stray", "resnet_bisect", "resnet_sites"):
+if mode in ("resnet", "resnet_stray", "resnet_bisect"):
     from types import SimpleNamespace
     from salve_amd.models.early_fusion import EarlyFusionCEResnet
     torch.manual_seed(0)
@@ -103,32 +103,6 @@ if mode.startswith("op_"):
         torch.cuda.synchronize()
         d = (out != ref).reshape(n, -1).any(1).nonzero().flatten().tolist()
         print(mode, "rep", rep, "renders differing:", d)
-
-if mode == "resnet_sites":
-    ras.cfg.reserved1 = 16
-    out0, dbg0 = ras.render(d_rgb, d_depth, hd, n, debug=True); torch.cuda.synchronize()
-    m0 = dbg0.mask.clone(); k0 = dbg0.keys.clone(); h0 = dbg0.img_xy.clone()
-    for rep in range(4):
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                y = eng.forward_nhwc(x)
-        out, dbg = ras.render(d_rgb, d_depth, hd, n, debug=True)
-        torch.cuda.synchronize()
-        dm = (dbg.mask != m0)
-        idx = dm.reshape(n, -1).any(1).nonzero().flatten().tolist()
-        sites = (m0 >= 100)
-        hd_ = (dbg.img_xy.reshape(n, -1, 2)[:, :501 * 501] != h0.reshape(n, -1, 2)[:, :501 * 501]).any(-1).reshape(n, 501, 501) & sites
-        print("   sites whose row-read hash differs:", int(hd_.sum()), " sites whose outcome differs:", int(dm.sum()), " both:", int((hd_ & dm).sum()))
-        print("rep", rep, "renders with differing site outcomes:", idx, "bev differ:", (out != out0).reshape(n, -1).any(1).nonzero().flatten().tolist())
-        for r in idx[:3]:
-            ys, xs = dm[r].nonzero(as_tuple=True)
-            for yy, xx in list(zip(ys.tolist(), xs.tolist()))[:4]:
-                occ = (k0[r].reshape(501, 501) != 0)
-                y0_, y1_, x0_, x1_ = max(0, yy - 4), min(501, yy + 5), max(0, xx - 6), min(501, xx + 7)
-                pid = yy * 501 + xx
-                print("   render", r, "site", (xx, yy), "outcome", int(dbg.mask[r, yy, xx]), "vs", int(m0[r, yy, xx]),
-                      "row-read hash", dbg.img_xy[r, pid].tolist(), "vs", h0[r, pid].tolist())
-                print("\n".join("      " + "".join("#" if occ[a, b] else "." for b in range(x0_, x1_)) for a in range(y0_, y1_)))
 
 if mode.startswith("burn") and mode[4:].isdigit():
     import ctypes
