@@ -26,7 +26,7 @@
 #include "../../include/salve_hip.h"
 #if defined(SALVE_PROFILE_WALK)
 // development build: count the general walk's work in LDS (read back through dbg_stats slots 1, 2, 3)
-enum { SDC_apex = 0, SDC_apex_slow, SDC_apex_far, SDC_rows, SDC_bits, SDC_exact, SDC_apex_table, SDC_N };
+enum { SDC_apex = 0, SDC_apex_slow, SDC_apex_far, SDC_rows, SDC_bits, SDC_exact, SDC_apex_table, SDC_apex_cached, SDC_N };
 __shared__ int sd_counters[SDC_N];
 #define SD_COUNT(c) atomicAdd(&sd_counters[SDC_##c], 1)
 // ... and where its time goes: wave-clock laps (units of 16 cycles), lane 0 of each wave
@@ -315,6 +315,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     const int Hp = (H + 1) & ~1;  // keep the int32 scalars 4-byte aligned behind the two int16 arrays
     int16_t* rmax = rmin + Hp;
     int* scal = reinterpret_cast<int*>(rmax + Hp);  // [0] n_sites [1] min x [2] max x [3] rows [4] steps [5] err
+    unsigned long long* tri_cache = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(scal + 16) + 7) & ~(uintptr_t)7);  // SD_CACHE_SIZE entries
 
     const int rid = blockIdx.x;
     const uint32_t* keys = keys_all + (size_t)rid * H * W;
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     if (tid < SDC_N) sd_counters[tid] = 0;
     if (tid < SDP_N) sd_timers[tid] = 0;
 #endif
+    for (int i = tid; i < SD_CACHE_SIZE; i += DENSIFY_THREADS) tri_cache[i] = 0ull;
     if (tid < 16) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : (tid == 12 ? H : (tid == 13 ? -1 : 0)));  // [12] min y [13] max y  // [6] site cursor [7] hard sites [8] queued triangles
     __syncthreads();
 
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     //      E2: hard sites (hull, sparse regions: a few %) walk their star with the general algorithm and rasterise
     //          in place.   F: all lanes rasterise the queued triangles.
     if (!degenerate && !(c.dbg_flags & 1)) {
-        SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13]};
+        SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13], (H <= 1024 && W <= 1024 && !(c.dbg_flags & 256)) ? tri_cache : nullptr};
         RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (c.dbg_flags & 2) != 0};
         QueueEmit qemit = {triq, &scal[8], H * W, raster};
         SdLean st;
@@ -502,9 +504,20 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             RasterEmit rw = raster;
             rw.lane = lane;
             rw.nlanes = 64;
-            for (int i = wave; i < ((c.dbg_flags & 4) ? 0 : nhard); i += nwaves) {
-                const uint32_t s = __hip_atomic_load(hardlist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sd_star(gw, (int)(s & 0xFFFFu), (int)(s >> 16), rw) < 0) err = 1;
+            // A wavefront takes HARD_RUN consecutive list entries at a time: neighbours in the list are neighbours in the
+            // image (the lean walk met them in raster order), and one wave walking them one after the other finds the
+            // triangles of the previous site in the cache instead of racing another wave for them.
+            constexpr int HARD_RUN = 8;
+            const int nh = (c.dbg_flags & 4) ? 0 : nhard;
+            for (;;) {
+                int i0 = 0;
+                if (lane == 0) i0 = atomicAdd(&scal[11], HARD_RUN);
+                i0 = __builtin_amdgcn_readfirstlane(i0);
+                if (i0 >= nh) break;
+                for (int i = i0; i < min(i0 + HARD_RUN, nh); i++) {
+                    const uint32_t s = __hip_atomic_load(hardlist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sd_star(gw, (int)(s & 0xFFFFu), (int)(s >> 16), rw) < 0) err = 1;
+                }
             }
         }
 #if defined(SALVE_PROFILE_WALK)
@@ -540,7 +553,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     if (dbg_stats) {
         __syncthreads();
 #if defined(SALVE_PROFILE_WALK)
-        if (tid < 8) dbg_stats[rid * 8 + tid] = (c.dbg_flags & 64) ? sd_timers[tid] : (tid < 7 ? sd_counters[tid] : scal[7]);
+        if (tid < 8) dbg_stats[rid * 8 + tid] = (c.dbg_flags & 64) ? sd_timers[tid] : sd_counters[tid];
 #else
         if (tid < 8) dbg_stats[rid * 8 + tid] = tid == 1 ? scal[9] : (tid == 2 ? scal[10] : (tid < 6 ? scal[tid] : scal[tid + 1]));  // [1] sites begun [2] checksum [6] hard sites [7] queued triangles
 #endif
@@ -740,7 +753,7 @@ bool make_devcfg(const salve_bev_config_t* cfg, DevCfg* d) {
 }
 
 size_t densify_lds_bytes(const DevCfg& d) {
-    return (size_t)2 * d.H * d.wpr * 4 + (size_t)2 * ((d.H + 1) & ~1) * 2 + 64;
+    return (size_t)2 * d.H * d.wpr * 4 + (size_t)2 * ((d.H + 1) & ~1) * 2 + 64 + 8 + (size_t)SD_CACHE_SIZE * 8;
 }
 
 }  // namespace

@@ -36,7 +36,43 @@ struct SdGrid {
     int lane, nlanes;     // 0, 1 for a caller that sweeps alone
     const int8_t* tab;    // SdTable (star_table.h) or nullptr: apex candidates of short edges, best first
     int bx0, bx1, by0, by1;  // bounding box of all sites (inclusive)
+    // Optional cache of resolved Delaunay triangles, shared by all callers working on this grid (LDS in the kernel):
+    // directed edge (u -> v) -> the apex on its left, one 64-bit word per entry, direct-mapped, SD_CACHE_SIZE entries
+    // (0 = empty).  Every triangle found serves three directed edges; along the outline of the point cloud, where the
+    // general walk is needed, neighbouring sites ask for the same triangles: about half of the sweeps are avoided.
+    unsigned long long* cache;  // or nullptr; requires H, W <= 1024
 };
+
+#define SD_CACHE_SIZE 1536
+
+SD_FN unsigned long long sd_cache_key(int ux, int uy, int vx, int vy) {
+    return (unsigned long long)ux | ((unsigned long long)uy << 10) | ((unsigned long long)vx << 20) | ((unsigned long long)vy << 30);
+}
+SD_FN int sd_cache_slot(unsigned long long key) {
+    const unsigned long long h = (key * 0x9E3779B97F4A7C15ull) >> 32;  // 32 well-mixed bits -> [0, SD_CACHE_SIZE)
+    return (int)((h * (unsigned long long)SD_CACHE_SIZE) >> 32);
+}
+
+// apex on the left of u -> v, if some walk has already resolved that triangle
+SD_FN bool sd_cache_lookup(const SdGrid& g, int ux, int uy, int vx, int vy, int* px, int* py) {
+    if (g.cache == nullptr) return false;
+    const unsigned long long key = sd_cache_key(ux, uy, vx, vy);
+    const unsigned long long e = g.cache[sd_cache_slot(key)];
+    if ((e >> 20) != key || e == 0ull) return false;
+    *px = (int)(e & 1023u);
+    *py = (int)((e >> 10) & 1023u);
+    return true;
+}
+
+// triangle (u, v, p), counter-clockwise: three directed edges, each with the third vertex on its left.  One lane
+// writes; an 8-byte LDS store is indivisible, so a concurrent reader sees an old or a new entry, never a mixture.
+SD_FN void sd_cache_insert(const SdGrid& g, int ux, int uy, int vx, int vy, int px, int py) {
+    if (g.cache == nullptr || g.lane != 0) return;
+    const unsigned long long k0 = sd_cache_key(ux, uy, vx, vy), k1 = sd_cache_key(vx, vy, px, py), k2 = sd_cache_key(px, py, ux, uy);
+    g.cache[sd_cache_slot(k0)] = (k0 << 20) | (unsigned long long)px | ((unsigned long long)py << 10);
+    g.cache[sd_cache_slot(k1)] = (k1 << 20) | (unsigned long long)ux | ((unsigned long long)uy << 10);
+    g.cache[sd_cache_slot(k2)] = (k2 << 20) | (unsigned long long)vx | ((unsigned long long)vy << 10);
+}
 
 // Table of apex candidates for short edges (built by star_table.h): for the edge vector (ax, ay) from the origin, the
 // lattice points strictly left of the edge in the order in which a circle through the edge's end points, grown to the
@@ -416,6 +452,12 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         }
     }
     if (sd_side_is_empty(g, sx, sy, ax, ay, dir)) return false;
+    // the side `dir` of s -> a is the left of (u -> v) = (s -> a) or (a -> s)
+    const int ux = dir > 0 ? sx : ax, uy = dir > 0 ? sy : ay, vx = dir > 0 ? ax : sx, vy = dir > 0 ? ay : sy;
+    if (sd_cache_lookup(g, ux, uy, vx, vy, outx, outy)) {
+        SD_COUNT(apex_cached);
+        return true;
+    }
     const SdEdge edge = sd_edge(sx, sy, ax, ay, dir);
     SdBest best;
     best.px = best.py = -1;
@@ -473,6 +515,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     }
     *outx = best.px;
     *outy = best.py;
+    sd_cache_insert(g, ux, uy, vx, vy, best.px, best.py);
     return true;
 }
 

@@ -12,6 +12,9 @@ static const int8_t* host_table() {
 }
 extern "C" int star_host_table_ok() { return host_table() != nullptr; }
 static int g_use_table = 1;
+static int g_cache_on = 0;
+static unsigned long long g_cache_mem[SD_CACHE_SIZE];
+extern "C" void star_host_use_cache(int on) { g_cache_on = on; memset(g_cache_mem, 0, sizeof(g_cache_mem)); }
 extern "C" void star_host_use_table(int on) { g_use_table = on; }
 
 struct Collect {
@@ -26,6 +29,7 @@ extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H,
                                      long long* total_steps) {
     const bool use_table = g_use_table != 0;
     if (use_table && !host_table()) return -3;
+    if (g_cache_on) memset(g_cache_mem, 0, sizeof(g_cache_mem));  // entries are only valid for one point set
     int wpr = (W + 31) / 32;
     std::vector<uint32_t> occ((size_t)H * wpr, 0);
     std::vector<int16_t> rmin(H, (int16_t)W), rmax(H, (int16_t)-1);
@@ -41,7 +45,7 @@ extern "C" int star_host_triangulate(const int* xs, const int* ys, int n, int H,
         if (ys[i] < by0) by0 = ys[i];
         if (ys[i] > by1) by1 = ys[i];
     }
-    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr, bx0, bx1, by0, by1};
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr, bx0, bx1, by0, by1, g_cache_on ? g_cache_mem : nullptr};
     std::vector<int> out;
     Collect c = {&out};
     long long steps = 0;
@@ -65,6 +69,7 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
                                            long long* stats) {
     const bool use_table = g_use_table != 0;
     if (use_table && !host_table()) return -3;
+    if (g_cache_on) memset(g_cache_mem, 0, sizeof(g_cache_mem));  // entries are only valid for one point set
     int wpr = (W + 31) / 32;
     std::vector<uint32_t> occ((size_t)H * wpr, 0);
     std::vector<int16_t> rmin(H, (int16_t)W), rmax(H, (int16_t)-1);
@@ -78,7 +83,7 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
         if (ys[i] < by0) by0 = ys[i];
         if (ys[i] > by1) by1 = ys[i];
     }
-    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr, bx0, bx1, by0, by1};
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, use_table ? host_table() : nullptr, bx0, bx1, by0, by1, g_cache_on ? g_cache_mem : nullptr};
     std::vector<int> out;
     Collect c = {&out};
     long long iters = 0, hard = 0, maxit = 0;

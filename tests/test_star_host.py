@@ -80,6 +80,21 @@ def test_structured_degenerate_sets(lib):
                 assert run(getattr(lib, which), pts, G, G)[0] == ref
 
 
+def test_triangle_cache(lib):
+    """The shared cache of resolved triangles (sd_cache_*) changes which queries sweep, never the result."""
+    rng = np.random.default_rng(11)
+    for _ in range(60):
+        G = int(rng.integers(20, 120))
+        pts = np.unique(rng.integers(0, G, size=(int(rng.integers(30, 400)), 2)), axis=0)
+        if bo._is_degenerate(pts):
+            continue
+        ref = oracle_tris(pts)
+        for which in ("star_host_triangulate", "star_host_triangulate_local"):
+            lib.star_host_use_cache(1)
+            assert run(getattr(lib, which), pts, G, G)[0] == ref
+    lib.star_host_use_cache(0)
+
+
 def test_realistic_render_sites(lib):
     hyp = synthetic.make_hypotheses(16, 2, seed=0)
     p0, p1 = synthetic.make_pano(0), synthetic.make_pano(1)

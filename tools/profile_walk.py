@@ -25,7 +25,7 @@ hd = ras.upload_hypotheses(pack_hypotheses(hyp.i1[:n], np.zeros(n), hyp.R[:n], h
 bev, dbg = ras.render(d_rgb, d_depth, hd, n, debug=True)
 torch.cuda.synchronize()
 st = dbg.stats.cpu().numpy().astype(np.float64)
-names = ["apex", "apex_slow", "apex_far", "rows", "bits", "exact", "apex_table", "hard_sites"]
+names = ["apex", "apex_slow", "apex_far", "rows", "bits", "exact", "apex_table", "apex_cached"]
 print({k: round(v, 1) for k, v in zip(names, st.mean(0))})
 ras.cfg.reserved1 = 64
 bev, dbg = ras.render(d_rgb, d_depth, hd, n, debug=True)
