@@ -125,6 +125,25 @@ def test_logits_match_oracle(num_layers, modalities, batch):
     assert (got.argmax(1) == ref.argmax(1)).all() or err < 1e-2
 
 
+def test_fused_bottleneck_is_bit_identical_to_three_kernels(monkeypatch):
+    """The fused bottleneck kernel (resnet.hip: bottleneck_kernel) keeps t1 / t2 in LDS but rounds them to bf16 and
+    accumulates in the same k order as the three separate convolutions: the logits must agree bit for bit."""
+    torch.manual_seed(5)
+    model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"]))
+    randomise_bn(model, seed=5)
+    model.eval()
+    x = torch.randn(3, 224, 224, 8).to(torch.bfloat16).to(DEV)
+    x[..., 6:] = 0
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SALVE_RESNET_FUSE", fuse)   # read when the handle is created
+        eng = hip_resnet.HipResNet(model.state_dict(), 50, torch.device(DEV))
+        outs.append(eng.forward_nhwc(x).clone())
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_forward_refuses_cpu_and_bad_modalities():
     model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["layout"])).eval()
     x = torch.zeros(1, 3, 224, 224)
