@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 # HBM bytes of one bev_densify_kernel launch of 512 renders from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate
 # passes, KiB units; profiles/r01_pmc_traffic.md).  The kernel reads 4 B / lane, for which FETCH_SIZE is uncalibrated:
 # the read side is taken as counted (lower bound).
-DENSIFY_TRAFFIC_BYTES_PER_RENDER = (610310 + 1053995) * 1024 / 512  # measured on launches of 512 renders; one workgroup per render
+DENSIFY_TRAFFIC_BYTES_PER_RENDER = (472007 + 937658) * 1024 / 512  # measured on launches of 512 renders; one workgroup per render
 
 
 def cpu_baseline(n_hyp: int, procs: int):
