@@ -1,0 +1,50 @@
+"""One-off wide parity sweep (GPU box): N random hypotheses x {floor, ceiling} over several panoramas, final BEV images
+bit for bit against the oracle's exact mode, oracle renders in a process pool.  python tools/parity_sweep.py [N] [procs]"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import multiprocessing as mp
+import numpy as np
+
+
+def oracle_one(args):
+    from oracle import bev_oracle as bo
+    from salve_amd import synthetic
+    pi, surface, R, t = args
+    rgb, depth = synthetic.make_pano(pi)
+    a = bo.xyzrgb_from_arrays(depth, rgb, bo.floor_ceiling_z_range(surface))
+    a, _ = bo.pose_pair(a, a[:1], R, t)
+    res = bo.render_bev_image(a, mode="exact")
+    return None if res is None else res["bev"]
+
+
+if __name__ == "__main__":
+    import torch
+    from salve_amd import synthetic
+    from salve_amd.rasteriser import BevRasteriser, pack_hypotheses
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+    procs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    P = 6
+    hyp = synthetic.make_hypotheses(N, P, seed=123)
+    surf = np.arange(N) % 2
+    jobs = [(int(hyp.i1[j]), "floor" if surf[j] == 0 else "ceiling", hyp.R[j], hyp.t[j]) for j in range(N)]
+    t0 = time.time()
+    with mp.get_context("spawn").Pool(procs) as pool:
+        ref = pool.map(oracle_one, jobs, chunksize=2)
+    print(f"oracle: {time.time() - t0:.0f} s for {N} renders", flush=True)
+    dev = torch.device("cuda:0")
+    ras = BevRasteriser(dev)
+    panos = [synthetic.make_pano(i) for i in range(P)]
+    d_rgb, d_depth = ras.upload_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
+    h = pack_hypotheses(hyp.i1, surf, hyp.R, hyp.t, np.ones(N))
+    bad = 0
+    for rep in range(3):   # repeated: the triangle cache and the work distribution are timing dependent
+        bev = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), N)[0]
+        got = ras.export_u8(bev).cpu().numpy()
+        for j in range(N):
+            exp = ref[j] if ref[j] is not None else np.zeros((501, 501, 3), np.uint8)
+            if not np.array_equal(got[j], exp):
+                bad += 1
+                print("MISMATCH rep", rep, "render", j, jobs[j][:2], int((got[j] != exp).any(-1).sum()), "pixels", flush=True)
+    print("renders compared:", 3 * N, "mismatches:", bad)
+    sys.exit(1 if bad else 0)
