@@ -109,3 +109,33 @@ def test_score_floor_fused_equals_unfused(tmp_path):
                 probs = torch.softmax(model.cuda()(x[0][None], x[1][None], None, None, None, None), 1)[0]
             y, p = fused_by_name[a]
             assert abs(float(probs[y]) - p) < 0.1
+
+
+def test_batched_floor_renderer_writes_the_same_files_as_the_pairwise_one(tmp_path):
+    """render_dataset.render_building_floor_pairs (one GPU batch per floor) against bev_rendering_utils.
+    generate_texture_maps_for_pair called once per (hypothesis, surface), as scripts/render_dataset_bev.py does: same
+    file set, same bytes; and a second call writes nothing (skip-if-exists)."""
+    from salve_amd import render_dataset
+    from salve_amd.utils import bev_rendering_utils as bru
+
+    raw, depth_root, hyp_root, _ = make_floor(tmp_path)
+    n = render_dataset.render_pairs(1, str(depth_root), str(tmp_path / "bev_batched"), str(raw), str(hyp_root), None, ["rgb_texture"],
+                                    None, "0003", device=DEV)
+    hyps = ingest.load_floor_hypotheses(str(hyp_root), "0003", "floor_01")
+    img_fpaths = ingest.floor_pano_fpaths(str(raw), "0003")
+    for j in range(len(hyps)):
+        label = "gt_alignment_approx" if hyps.label[j] else "incorrect_alignment"
+        for surface in ("floor", "ceiling"):
+            bru.generate_texture_maps_for_pair(img_fpaths, surface, hyps.fpaths[j], int(hyps.pair_idx[j]), label, str(tmp_path / "bev_pairwise"),
+                                               "0003", "floor_01", str(depth_root), ["rgb_texture"], None, None)
+    a = sorted(p.relative_to(tmp_path / "bev_batched") for p in (tmp_path / "bev_batched").rglob("*.jpg"))
+    b = sorted(p.relative_to(tmp_path / "bev_pairwise") for p in (tmp_path / "bev_pairwise").rglob("*.jpg"))
+    assert a == b and len(a) == n and n > 0
+    for rel in a:
+        assert (tmp_path / "bev_batched" / rel).read_bytes() == (tmp_path / "bev_pairwise" / rel).read_bytes()
+    assert render_dataset.render_building_floor_pairs(str(depth_root), str(tmp_path / "bev_batched"), str(hyp_root), str(raw), "0003", "floor_01",
+                                                      None, ["rgb_texture"], device=DEV) == 0
+    with pytest.raises(ValueError):
+        render_dataset.render_pairs(1, "", "", "", "", None, ["rgb_texture"], "train", "0003")
+    with pytest.raises(NotImplementedError):
+        render_dataset.render_building_floor_pairs("", "", "", "", "0003", "floor_01", None, ["layout"])
