@@ -339,21 +339,45 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     // ---- phase B: bitmaps by wave ballot (no LDS atomics), row extents, compact site list.
     //      `msk` receives the horizontally dilated "non-empty" bits (uint8 channel product wraps mod 256).
     const int nseg = (W + 63) >> 6;
+    constexpr int ROW_SEGS = 8;  // rows of up to 512 pixels are fetched whole: all key loads, then all colour gathers, in flight together
     for (int y = wave; y < H; y += nwaves) {
         int lo = W, hi = -1;
         unsigned long long ne_prev = 0, ne_cur = 0;
+        uint32_t row_key[ROW_SEGS], row_col[ROW_SEGS];
+        const bool whole_row = nseg <= ROW_SEGS;
+        if (whole_row) {
+            // Two memory round trips per row instead of two per 64-pixel segment: this phase is nothing but latency.
+#pragma unroll
+            for (int sg = 0; sg < ROW_SEGS; sg++) {
+                const int x = (sg << 6) + lane;
+                row_key[sg] = (sg < nseg && x < W) ? load_key(keys + (size_t)y * W + x) : 0u;
+            }
+#pragma unroll
+            for (int sg = 0; sg < ROW_SEGS; sg++) {
+                uint32_t col = 0;
+                if (row_key[sg] != 0u) {  // the winning point's colour, from its source array (panorama or point list: L2-resident)
+                    const uint8_t* cs = colours + 3 * (size_t)(row_key[sg] & KEY_INDEX_MASK);
+                    col = (uint32_t)cs[0] | ((uint32_t)cs[1] << 8) | ((uint32_t)cs[2] << 16);
+                }
+                row_col[sg] = col;
+            }
+        }
         for (int seg = 0; seg <= nseg; seg++) {
             unsigned long long ob = 0, ne_next = 0;
             if (seg < nseg) {
                 const int x = (seg << 6) + lane;
-                uint32_t key = 0;
-                if (x < W) key = load_key(keys + (size_t)y * W + x);
-                const bool site = key != 0;
-                uint32_t col = 0;
-                if (site) {  // the winning point's colour, from its source array (panorama or point list: L2-resident)
-                    const uint8_t* cs = colours + 3 * (size_t)(key & KEY_INDEX_MASK);
-                    col = (uint32_t)cs[0] | ((uint32_t)cs[1] << 8) | ((uint32_t)cs[2] << 16);
+                uint32_t key = 0, col = 0;
+                if (whole_row) {
+                    key = row_key[seg & (ROW_SEGS - 1)];
+                    col = row_col[seg & (ROW_SEGS - 1)];
+                } else {
+                    if (x < W) key = load_key(keys + (size_t)y * W + x);
+                    if (key != 0u) {
+                        const uint8_t* cs = colours + 3 * (size_t)(key & KEY_INDEX_MASK);
+                        col = (uint32_t)cs[0] | ((uint32_t)cs[1] << 8) | ((uint32_t)cs[2] << 16);
+                    }
                 }
+                const bool site = key != 0;
                 // the output image starts as the sparse image: data pixels carry their colour (they are also the vertex
                 // colours the rasteriser reads back), everything else is 0
                 if (x < W) bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = col;
