@@ -194,6 +194,12 @@ typedef struct {
     int64_t w_off;    /* CONV: element offset into the bf16 weight blob; FC: float offset of the weight in params */
     int64_t b_off;    /* float offset of the bias in params */
     int64_t ktab_off; /* CONV: offset into ktab; one int32 per 8 consecutive k: dy | dx << 8 | channel_offset << 16 */
+    /* Optional second, point-wise source of a 1x1 / stride-1 CONV (in2_buf = SALVE_NO_BUF: none): the weight rows are
+     * [Cin | Cin2] long and the k-tiles beyond Cin read Cin2 channels of buffer in2 (an [Hi2, Wi2, Cin2] image) at pixel
+     * (oy * stride2, ox * stride2).  This is how the projection shortcut of a down-sampling bottleneck block
+     * (torchvision `downsample` = 1x1 conv + BN) is folded into the block's last convolution: one GEMM over the
+     * concatenated channels instead of a convolution, a tensor written and read back, and a residual add. */
+    int32_t in2_buf, Cin2, stride2, Hi2, Wi2, reserved2;
 } salve_resnet_op_t;
 
 /* Creates a handle that owns device copies of the (host) weight blobs.  NULL on failure. */

@@ -38,6 +38,9 @@ struct ConvArgs {
     const uint16_t* zeros;  // >= 16 zero bytes: the source of padding taps and of rows beyond M
     int B, Hi, Wi, Cin, Ho, Wo, Cout, stride, pad, K, M, relu;
     int m_tiles, n_tiles;
+    // second, point-wise source (SRC2 kernels): k-tiles from nkt1 on read Cin2 channels of in2 at (oy, ox) * stride2
+    const uint16_t* in2;
+    int Hi2, Wi2, Cin2, stride2, nkt1;
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
@@ -60,7 +63,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // (64 KB, two workgroups per CU) by 25-45 %: occupancy, not explicit pipelining, is what this tile size wants.
 // POINTWISE: 1x1 / stride 1 / pad 0 -- output pixel m reads input pixel m, so the im2col index arithmetic (three integer
 // divisions per staged row, bounds checks per k-tile) disappears; these are 32 of ResNet-50's 53 convolutions.
-template <int BN, bool POINTWISE>
+// SRC2 (with POINTWISE): the GEMM runs over the concatenated channels of two tensors -- see `in2_buf` in salve_hip.h.
+template <int BN, bool POINTWISE, bool SRC2 = false>
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p) {
     constexpr int WN = BN / 2;       // wave tile width
     constexpr int NT = WN / 16;      // 16-wide MFMA tiles per wave along n
@@ -90,10 +94,16 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     int iy0[4], ix0[4];
     long long boff[4];
     const uint16_t* rowp[4];  // POINTWISE: the input pixel's channels (or the zero page, with stride 0)
+    const uint16_t* rowp2[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int m = m0 + row_base + i * 32;
         const bool valid = m < p.M;
+        rowp2[i] = nullptr;
+        if (SRC2 && valid) {
+            const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+            rowp2[i] = p.in2 + (((long long)b * p.Hi2 + (long long)oy * p.stride2) * p.Wi2 + (long long)ox * p.stride2) * p.Cin2 + chunk * 8;
+        }
         if (POINTWISE) {
             rowp[i] = valid ? p.in + (long long)m * p.Cin + chunk * 8 : nullptr;
             iy0[i] = ix0[i] = 0;
@@ -124,7 +134,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
         const int dy_ = (int8_t)((E) & 0xFF), dx_ = (int8_t)(((E) >> 8) & 0xFF), coff_ = ((E) >> 16) & 0xFFFF;          \
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                \
             const uint16_t* src;                                                                                       \
-            if (POINTWISE) {                                                                                           \
+            if (SRC2 && (KT) >= p.nkt1) {                                                                              \
+                src = rowp2[i] ? rowp2[i] + ((KT) - p.nkt1) * BK : p.zeros;                                            \
+            } else if (POINTWISE) {                                                                                    \
                 src = rowp[i] ? rowp[i] + (KT) * BK : p.zeros;                                                         \
             } else {                                                                                                   \
                 const int iy = iy0[i] + dy_, ix = ix0[i] + dx_;                                                        \
@@ -637,6 +649,12 @@ bool check_op(const salve_resnet_op_t& o) {
         if (o.Cout % 64 != 0) return salve_fail("conv: Cout must be a multiple of 64");
         if (o.Cin % 8 != 0) return salve_fail("conv: Cin must be a multiple of 8");
         if ((o.KH * o.KW * o.Cin) % BK != 0) return salve_fail("conv: KH*KW*Cin must be a multiple of 64");
+        if (o.in2_buf != SALVE_NO_BUF) {
+            if (o.KH != 1 || o.KW != 1 || o.stride != 1 || o.pad != 0 || o.res_buf != SALVE_NO_BUF)
+                return salve_fail("conv: a second source needs a 1x1 / stride 1 / pad 0 convolution without residual");
+            if (o.Cin2 <= 0 || o.Cin2 % BK != 0 || o.stride2 < 1 || (o.Hi2 - 1) / o.stride2 + 1 != o.Ho || (o.Wi2 - 1) / o.stride2 + 1 != o.Wo)
+                return salve_fail("conv: bad second-source geometry");
+        }
     } else if (o.op == SALVE_OP_MAXPOOL) {
         if (o.Cin % 8 != 0) return salve_fail("maxpool: C must be a multiple of 8");
     } else if (o.op == SALVE_OP_AVGPOOL_FC) {
@@ -684,7 +702,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
             const int mid = a.Cout;
             const bool shapes = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.relu && a.res_buf == SALVE_NO_BUF && a.Cin == 4 * mid &&
                                 b.KH == 3 && b.KW == 3 && b.stride == 1 && b.pad == 1 && b.relu && b.res_buf == SALVE_NO_BUF && b.Cin == mid && b.Cout == mid &&
-                                b.in_buf == a.out_buf && c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad == 0 && c.relu && c.Cin == mid &&
+                                b.in_buf == a.out_buf && a.in2_buf == SALVE_NO_BUF && c.in2_buf == SALVE_NO_BUF && c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad == 0 && c.relu && c.Cin == mid &&
                                 c.Cout == 4 * mid && c.in_buf == b.out_buf && c.res_buf == a.in_buf && c.out_buf != a.in_buf && a.in_buf >= 0 &&
                                 a.Hi == c.Ho && a.Wi == c.Wo && b.Hi == a.Hi && b.Ho == a.Hi;
             // measured at batch 512: the 64-channel blocks (56 x 56) gain 15 % fused; the 128-channel blocks (28 x 28, 4 x 16
@@ -696,7 +714,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
                 const int id = which ? b.out_buf : a.out_buf;
                 for (size_t k = i + 3; k < h->ops.size(); k++) {
                     const salve_resnet_op_t& o = h->ops[k];
-                    if (o.in_buf == id || (o.op == SALVE_OP_CONV && o.res_buf == id)) { dead = false; break; }
+                    if (o.in_buf == id || (o.op == SALVE_OP_CONV && (o.res_buf == id || o.in2_buf == id))) { dead = false; break; }
                     if (o.out_buf == id) break;
                 }
             }
@@ -786,6 +804,11 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.zeros = h->d_zeros;
             a.B = batch; a.Hi = o.Hi; a.Wi = o.Wi; a.Cin = o.Cin; a.Ho = o.Ho; a.Wo = o.Wo; a.Cout = o.Cout;
             a.stride = o.stride; a.pad = o.pad; a.K = o.KH * o.KW * o.Cin; a.relu = o.relu;
+            const bool src2 = o.in2_buf != SALVE_NO_BUF;
+            a.in2 = src2 ? buf(o.in2_buf) : nullptr;
+            a.Hi2 = o.Hi2; a.Wi2 = o.Wi2; a.Cin2 = o.Cin2; a.stride2 = o.stride2;
+            a.nkt1 = a.K / BK;
+            if (src2) a.K += o.Cin2;
             const long long M = (long long)batch * o.Ho * o.Wo;
             if (M > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
             a.M = (int)M;
@@ -794,7 +817,11 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.n_tiles = o.Cout / bn;
             const unsigned grid = (unsigned)(((a.m_tiles + 7) / 8) * 8 * a.n_tiles);
             const bool pointwise = o.KH == 1 && o.KW == 1 && o.stride == 1 && o.pad == 0;
-            if (bn == 128 && pointwise) {
+            if (src2 && bn == 128) {
+                hipLaunchKernelGGL((conv_igemm_kernel<128, true, true>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
+            } else if (src2) {
+                hipLaunchKernelGGL((conv_igemm_kernel<64, true, true>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
+            } else if (bn == 128 && pointwise) {
                 hipLaunchKernelGGL((conv_igemm_kernel<128, true>), dim3(grid), dim3(CONV_THREADS), 0, s, a);
             } else if (bn == 128) {
                 hipLaunchKernelGGL((conv_igemm_kernel<128, false>), dim3(grid), dim3(CONV_THREADS), 0, s, a);

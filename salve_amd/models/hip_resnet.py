@@ -22,9 +22,10 @@ BN_EPS = 1e-5
 OP_DTYPE = np.dtype(
     [("op", "<i4"), ("in_buf", "<i4"), ("out_buf", "<i4"), ("res_buf", "<i4"), ("Hi", "<i4"), ("Wi", "<i4"),
      ("Cin", "<i4"), ("Ho", "<i4"), ("Wo", "<i4"), ("Cout", "<i4"), ("KH", "<i4"), ("KW", "<i4"), ("stride", "<i4"),
-     ("pad", "<i4"), ("relu", "<i4"), ("reserved", "<i4"), ("w_off", "<i8"), ("b_off", "<i8"), ("ktab_off", "<i8")]
+     ("pad", "<i4"), ("relu", "<i4"), ("reserved", "<i4"), ("w_off", "<i8"), ("b_off", "<i8"), ("ktab_off", "<i8"),
+     ("in2_buf", "<i4"), ("Cin2", "<i4"), ("stride2", "<i4"), ("Hi2", "<i4"), ("Wi2", "<i4"), ("reserved2", "<i4")]
 )
-assert OP_DTYPE.itemsize == 88
+assert OP_DTYPE.itemsize == 112
 
 
 def pad_channels(c: int) -> int:
@@ -65,7 +66,7 @@ class _Builder:
         Ho = (Hi + 2 * pad - KH) // stride + 1
         Wo = (Wi + 2 * pad - KW) // stride + 1
         self.ops.append((OP_CONV, in_buf, out_buf, res_buf, Hi, Wi, Cinp, Ho, Wo, Cout, KH, KWp, stride, pad, int(relu), 0,
-                         self.w_elems, self.p_elems, self.k_elems))
+                         self.w_elems, self.p_elems, self.k_elems, NO_BUF, 0, 0, 0, 0, 0))
         self.weights.append(bits.reshape(-1))
         self.params.append(b.float().numpy().copy())
         self.ktab.append(tab)
@@ -74,9 +75,30 @@ class _Builder:
         self.k_elems += tab.size
         return Ho, Wo
 
+    def conv1x1_with_shortcut(self, w: torch.Tensor, b: torch.Tensor, in_buf: int, out_buf: int, Hi: int, Wi: int,
+                              w2: torch.Tensor, b2: torch.Tensor, in2_buf: int, Hi2: int, Wi2: int, stride2: int) -> None:
+        """relu(w . in + b + w2 . in2[::stride2, ::stride2] + b2) as ONE op: the last 1x1 convolution of a down-sampling
+        bottleneck block with the block's projection shortcut folded in (include/salve_hip.h, `in2_buf`).  The weight rows
+        are the concatenation [w | w2]; the two biases add."""
+        Cout, Cin = w.shape[:2]
+        Cin2 = w2.shape[1]
+        assert w.shape[2:] == (1, 1) and w2.shape[2:] == (1, 1) and Cin % 64 == 0 and Cin2 % 64 == 0 and Cout % 64 == 0
+        assert (Hi2 - 1) // stride2 + 1 == Hi and (Wi2 - 1) // stride2 + 1 == Wi
+        wcat = torch.cat([w.reshape(Cout, Cin), w2.reshape(Cout, Cin2)], dim=1).float()
+        bits = wcat.to(torch.bfloat16).view(torch.int16).numpy().copy()
+        tab = np.zeros((Cin + Cin2) // 8, dtype=np.int32)  # not read by the point-wise kernel
+        self.ops.append((OP_CONV, in_buf, out_buf, NO_BUF, Hi, Wi, Cin, Hi, Wi, Cout, 1, 1, 1, 0, 1, 0,
+                         self.w_elems, self.p_elems, self.k_elems, in2_buf, Cin2, stride2, Hi2, Wi2, 0))
+        self.weights.append(bits.reshape(-1))
+        self.params.append((b.float() + b2.float()).numpy().copy())
+        self.ktab.append(tab)
+        self.w_elems += bits.size
+        self.p_elems += Cout
+        self.k_elems += tab.size
+
     def maxpool(self, in_buf: int, out_buf: int, Hi: int, Wi: int, C: int) -> Tuple[int, int]:
         Ho, Wo = (Hi + 2 - 3) // 2 + 1, (Wi + 2 - 3) // 2 + 1
-        self.ops.append((OP_MAXPOOL, in_buf, out_buf, NO_BUF, Hi, Wi, C, Ho, Wo, C, 3, 3, 2, 1, 0, 0, 0, 0, 0))
+        self.ops.append((OP_MAXPOOL, in_buf, out_buf, NO_BUF, Hi, Wi, C, Ho, Wo, C, 3, 3, 2, 1, 0, 0, 0, 0, 0, NO_BUF, 0, 0, 0, 0, 0))
         return Ho, Wo
 
     def fc(self, w: torch.Tensor, b: torch.Tensor, in_buf: int, Hi: int, Wi: int, C: int) -> None:
@@ -87,7 +109,7 @@ class _Builder:
         b_off = self.p_elems
         self.params.append(b.float().numpy().copy())
         self.p_elems += ncls
-        self.ops.append((OP_AVGPOOL_FC, in_buf, NO_BUF, NO_BUF, Hi, Wi, C, 1, 1, ncls, 1, 1, 1, 0, 0, 0, w_off, b_off, 0))
+        self.ops.append((OP_AVGPOOL_FC, in_buf, NO_BUF, NO_BUF, Hi, Wi, C, 1, 1, ncls, 1, 1, 1, 0, 0, 0, w_off, b_off, 0, NO_BUF, 0, 0, 0, 0, 0))
 
 
 def _bn(sd: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Tensor]:
@@ -118,12 +140,12 @@ def build_program(state_dict: Dict[str, torch.Tensor], num_layers: int, in_hw: T
                 wc, bc = fold_bn(sd[f"{p}.conv3.weight"], _bn(sd, f"{p}.bn3"))
                 b.conv(wa, ba, x, t1, NO_BUF, H, W, 1, 0, True)
                 Ho, Wo = b.conv(wb, bb, t1, t2, NO_BUF, H, W, stride, 1, True)
-                idn = x
                 if f"{p}.downsample.0.weight" in sd:
+                    # the projection shortcut rides along in the last convolution (one GEMM over [t2 | x] channels)
                     wd, bd = fold_bn(sd[f"{p}.downsample.0.weight"], _bn(sd, f"{p}.downsample.1"))
-                    b.conv(wd, bd, x, dsb, NO_BUF, H, W, stride, 0, False)
-                    idn = dsb
-                b.conv(wc, bc, t2, outb, idn, Ho, Wo, 1, 0, True)
+                    b.conv1x1_with_shortcut(wc, bc, t2, outb, Ho, Wo, wd, bd, x, H, W, stride)
+                else:
+                    b.conv(wc, bc, t2, outb, x, Ho, Wo, 1, 0, True)
             else:
                 wa, ba = fold_bn(sd[f"{p}.conv1.weight"], _bn(sd, f"{p}.bn1"))
                 wb, bb = fold_bn(sd[f"{p}.conv2.weight"], _bn(sd, f"{p}.bn2"))

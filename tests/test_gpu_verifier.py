@@ -125,6 +125,48 @@ def test_logits_match_oracle(num_layers, modalities, batch):
     assert (got.argmax(1) == ref.argmax(1)).all() or err < 1e-2
 
 
+@pytest.mark.parametrize("stride,hw,cx,mid,cout", [(1, 56, 64, 64, 256), (2, 28, 256, 128, 512)])
+def test_conv_with_projection_shortcut_as_second_source(stride, hw, cx, mid, cout):
+    """`in2_buf` of salve_resnet_op_t: relu(W . t2 + b + W2 . x[::s, ::s] + b2) as one GEMM over concatenated channels,
+    against torch (the down-sampling bottleneck's last convolution + projection shortcut)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7)
+    B = 2
+    wb3 = torch.randn(mid, cx, 3, 3, generator=g) * (2.0 / (cx * 9)) ** 0.5
+    bb3 = torch.randn(mid, generator=g) * 0.1
+    w = torch.randn(cout, mid, 1, 1, generator=g) * (1.0 / mid) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    w2 = torch.randn(cout, cx, 1, 1, generator=g) * (1.0 / cx) ** 0.5
+    b2 = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(B, cx, hw, hw, generator=g)
+    x_nhwc = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+    bld = hip_resnet._Builder()
+    Ho, Wo = bld.conv(wb3, bb3, hip_resnet.NET_INPUT, 0, hip_resnet.NO_BUF, hw, hw, stride, 1, True)
+    bld.conv1x1_with_shortcut(w, b, 0, 1, Ho, Wo, w2, b2, hip_resnet.NET_INPUT, hw, hw, stride)
+    ops = np.array(bld.ops, dtype=hip_resnet.OP_DTYPE)
+    wts, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
+    h = ctypes.c_void_p(lib.salve_resnet_create(0, cx, ops.ctypes.data_as(ctypes.c_void_p), len(ops), wts.ctypes.data_as(ctypes.c_void_p), wts.nbytes,
+                                                 pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
+    assert h
+    need = lib.salve_resnet_workspace_bytes(h, B)
+    ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
+    xd = x_nhwc.to(DEV)
+    logits = torch.zeros((B, 2), dtype=torch.float32, device=DEV)
+    st = lib.salve_resnet_forward(h, ctypes.c_void_p(xd.data_ptr()), B, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), None)
+    torch.cuda.synchronize()
+    assert st == 0, lib.salve_last_error()
+    per_buf = (need - 256) // 2 // 2                    # two buffers of bf16 elements
+    view = ws[(-ws.data_ptr()) % 256:].view(torch.bfloat16)
+    got = view[per_buf: per_buf + B * Ho * Wo * cout].float().cpu().reshape(B, Ho, Wo, cout)
+    lib.salve_resnet_destroy(h)
+    xr = x_nhwc.float().permute(0, 3, 1, 2)
+    t2 = torch.nn.functional.conv2d(xr, wb3.to(torch.bfloat16).float(), bb3, stride, 1).relu().to(torch.bfloat16).float()
+    ref = (torch.nn.functional.conv2d(t2, w.to(torch.bfloat16).float(), b) +
+           torch.nn.functional.conv2d(xr, w2.to(torch.bfloat16).float(), b2, stride)).relu().permute(0, 2, 3, 1)
+    err = (got - ref).abs()
+    assert (err <= 2e-2 * ref.abs().clamp(min=0.5)).all(), f"max err {err.max()}"
+
+
 def test_fused_bottleneck_is_bit_identical_to_three_kernels(monkeypatch):
     """The fused bottleneck kernel (resnet.hip: bottleneck_kernel) keeps t1 / t2 in LDS but rounds them to bf16 and
     accumulates in the same k order as the three separate convolutions: the logits must agree bit for bit."""

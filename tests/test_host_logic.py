@@ -150,11 +150,14 @@ def test_model_state_dict_layout_and_program():
     m = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"]))
     sd = {"module." + k: v for k, v in m.state_dict().items()}  # DataParallel checkpoints
     ops, w, p, k, cin_p = hip_resnet.build_program(sd, 50)
-    assert cin_p == 8 and len(ops) == 1 + 1 + 16 * 3 + 4 + 1
+    # stem conv + max-pool + 16 blocks x 3 convolutions + avg-pool/fc; the 4 projection shortcuts ride along in their
+    # block's last convolution as a second source (include/salve_hip.h: in2_buf)
+    assert cin_p == 8 and len(ops) == 1 + 1 + 16 * 3 + 1
     convs = ops[ops["op"] == 0]
+    assert (convs["in2_buf"] != hip_resnet.NO_BUF).sum() == 4
     assert (convs["Cout"] % 64 == 0).all() and ((convs["KH"] * convs["KW"] * convs["Cin"]) % 64 == 0).all()
-    assert convs["w_off"][-1] + convs["Cout"][-1] * convs["KH"][-1] * convs["KW"][-1] * convs["Cin"][-1] == w.size
-    flops = 2 * (convs["Ho"].astype(np.int64) * convs["Wo"] * convs["Cout"] * convs["KH"] * convs["KW"] * convs["Cin"]).sum()
+    assert convs["w_off"][-1] + convs["Cout"][-1] * (convs["KH"][-1] * convs["KW"][-1] * convs["Cin"][-1] + convs["Cin2"][-1]) == w.size
+    flops = 2 * (convs["Ho"].astype(np.int64) * convs["Wo"] * convs["Cout"] * (convs["KH"] * convs["KW"] * convs["Cin"] + convs["Cin2"])).sum()
     assert 8.3e9 < flops < 9.6e9  # 8.41 GFLOP algorithmic + the stem's zero padding
     assert tuple(ops[-1][["Hi", "Wi", "Cin", "Cout"]]) == (7, 7, 2048, 2)
 
