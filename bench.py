@@ -3,7 +3,7 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A step = one pass of the fused render+verify path over the rank's shard of the hypothesis table
-(BASELINE.json configs[2]: 4096 hypotheses over 64 synthetic 1024x512 panoramas, rasteriser + ResNet-50 bf16,
+(BASELINE.json configs[2]: 4096 hypotheses over 64 synthetic 1024x512 panoramas, rasteriser + ResNet-50 fp16,
 per GPU -> weak scaling).  Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 """
 
@@ -142,9 +142,9 @@ def main() -> None:
         out = {
             "metric": "alignment hypotheses/sec (render+verify)", "value": round(value, 2), "unit": "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
             "config": {"workload": f"{args.hyps} hypotheses/GPU over {args.panos} synthetic 1024x512 panoramas, floor surface, "
-                                   f"HIP BEV rasteriser + ResNet-{args.layers} (6-ch early fusion) bf16 MFMA verifier",
+                                   f"HIP BEV rasteriser + ResNet-{args.layers} (6-ch early fusion) fp16 MFMA verifier",
                        "hypotheses_per_gpu": args.hyps, "panos": args.panos, "renders_per_hypothesis": 1,
                        "cached_identity_renders": args.panos, "chunk": args.chunk, "parallelism": f"hypothesis-shard x{world}"},
             "roofline": {"kernel": "bev_densify_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,

@@ -156,7 +156,7 @@ int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t b
  *   coef_y/x    device int32 [resize, 4]: {src0, src1, w0, w1} 11-bit taps per resized row / column
  *   lut         device float [3, 256]: (v - mean_c) / std_c evaluated in float32 on the host
  *   out         SALVE_TILE_F32_NCHW : float [slots, out_c, crop, crop]
- *               SALVE_TILE_BF16_NHWC: bf16  [slots, crop, crop, out_c]
+ *               SALVE_TILE_F16_NHWC:  fp16  [slots, crop, crop, out_c]
  */
 typedef struct {
     int64_t bev_offset; /* element offset of the source image inside `bev` (uint32 units) */
@@ -165,20 +165,20 @@ typedef struct {
 } salve_tile_job_t;
 
 #define SALVE_TILE_F32_NCHW 0
-#define SALVE_TILE_BF16_NHWC 1
+#define SALVE_TILE_F16_NHWC 1
 
 int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs, int32_t n_jobs,
                     const int32_t* coef_y, const int32_t* coef_x, int32_t resize, int32_t crop, const float* lut,
                     void* out, int32_t out_format, int32_t out_c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Verifier: early-fusion ResNet forward pass (bf16 MFMA, fp32 accumulation).
+ * Verifier: early-fusion ResNet forward pass (fp16 MFMA, fp32 accumulation).
  * Stands behind salve/models/early_fusion.py:14-83 (EarlyFusionCEResnet), the torchvision trunk
  * selected by salve/models/resnet_factory.py:26-44, and the model build / checkpoint load of
  * salve/train_utils.py:205-242.  The host folds BatchNorm into the convolutions and describes the
  * network as a list of ops over a few activation buffers; the library executes the list.
  * ------------------------------------------------------------------------------------------------ */
-#define SALVE_OP_CONV 0       /* out = relu?(conv(in) + bias (+ res)) ; NHWC bf16 */
+#define SALVE_OP_CONV 0       /* out = relu?(conv(in) + bias (+ res)) ; NHWC fp16 */
 #define SALVE_OP_MAXPOOL 1    /* 3x3 / stride 2 / pad 1 */
 #define SALVE_OP_AVGPOOL_FC 2 /* global average pool + linear layer -> fp32 logits */
 #define SALVE_NET_INPUT (-1)  /* buffer id of the network input */
@@ -191,7 +191,7 @@ typedef struct {
     int32_t Ho, Wo, Cout;             /* output H, W, channels (FC: Cout = number of classes) */
     int32_t KH, KW, stride, pad;      /* KW is the PADDED kernel width of the packed weights */
     int32_t relu, reserved;
-    int64_t w_off;    /* CONV: element offset into the bf16 weight blob; FC: float offset of the weight in params */
+    int64_t w_off;    /* CONV: element offset into the fp16 weight blob; FC: float offset of the weight in params */
     int64_t b_off;    /* float offset of the bias in params */
     int64_t ktab_off; /* CONV: offset into ktab; one int32 per 8 consecutive k: dy | dx << 8 | channel_offset << 16 */
     /* Optional second, point-wise source of a 1x1 / stride-1 CONV (in2_buf = SALVE_NO_BUF: none): the weight rows are
@@ -204,13 +204,13 @@ typedef struct {
 
 /* Creates a handle that owns device copies of the (host) weight blobs.  NULL on failure. */
 void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,
-                          const void* weights_bf16, size_t weights_bytes, const float* params_f32, size_t params_bytes,
+                          const void* weights_f16, size_t weights_bytes, const float* params_f32, size_t params_bytes,
                           const int32_t* ktab, size_t ktab_entries);
 void salve_resnet_destroy(void* handle);
 int salve_resnet_num_layers(void* handle);
 /* Device workspace needed for a batch (activation buffers). */
 size_t salve_resnet_workspace_bytes(void* handle, int32_t batch);
-/* input: device bf16 [batch, H, W, in_channels] (NHWC); logits: device float [batch, n_classes]. */
+/* input: device fp16 [batch, H, W, in_channels] (NHWC); logits: device float [batch, n_classes]. */
 int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* logits, void* workspace,
                          size_t workspace_bytes, void* stream);
 

@@ -15,7 +15,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libsalve_hip.so"
 
 SALVE_OK = 0
 TILE_F32_NCHW = 0
-TILE_BF16_NHWC = 1
+TILE_F16_NHWC = 1
 
 # every symbol include/salve_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (

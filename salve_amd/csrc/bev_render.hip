@@ -585,11 +585,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ tiles
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (inputs are finite)
-    return (uint16_t)(u >> 16);
-}
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }  // |values| < 3: no saturation needed
 
 __global__ __launch_bounds__(256) void bev_tile_kernel(const uint32_t* __restrict__ bev, int W,
                                                        const salve_tile_job_t* __restrict__ jobs,
@@ -625,7 +621,7 @@ __global__ __launch_bounds__(256) void bev_tile_kernel(const uint32_t* __restric
     } else {
         uint16_t* o = reinterpret_cast<uint16_t*>(out) + ((size_t)job.slot * crop * crop + idx) * out_c + job.chan;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) o[ch] = f32_to_bf16(v[ch]);
+        for (int ch = 0; ch < 3; ch++) o[ch] = f32_to_f16(v[ch]);
     }
 }
 
@@ -997,7 +993,7 @@ int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const sal
         return SALVE_ERR_BAD_ARG;
     }
     if (crop <= 0 || resize < crop || out_c < 3) { salve_fail("salve_bev_tiles: need 0 < crop <= resize, out_c >= 3"); return SALVE_ERR_BAD_ARG; }
-    if (out_format != SALVE_TILE_F32_NCHW && out_format != SALVE_TILE_BF16_NHWC) { salve_fail("unknown tile format"); return SALVE_ERR_UNSUPPORTED; }
+    if (out_format != SALVE_TILE_F32_NCHW && out_format != SALVE_TILE_F16_NHWC) { salve_fail("unknown tile format"); return SALVE_ERR_UNSUPPORTED; }
     if (n_jobs > 65535) { salve_fail("at most 65535 tile jobs per call"); return SALVE_ERR_BAD_ARG; }
     dim3 g((crop * crop + 255) / 256, n_jobs);
     hipLaunchKernelGGL(bev_tile_kernel, g, dim3(256), 0, (hipStream_t)stream, bev, bev_w, jobs, coef_y, coef_x, resize, crop,

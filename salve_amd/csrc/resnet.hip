@@ -1,12 +1,12 @@
-// resnet.hip -- early-fusion ResNet verifier forward pass for gfx950 (MI355X), bf16 MFMA with fp32 accumulation.
+// resnet.hip -- early-fusion ResNet verifier forward pass for gfx950 (MI355X), fp16 MFMA with fp32 accumulation.
 //
 // Stands behind salve/models/early_fusion.py:41-83 (EarlyFusionCEResnet.forward) with the torchvision ResNet v1.5
 // trunk built by salve/models/resnet_factory.py:26-44.  The host (salve_amd/models) folds every BatchNorm into the
-// preceding convolution, packs weights as [Cout][KH][KWp][Cin] bf16 and hands the network over as a small "op
+// preceding convolution, packs weights as [Cout][KH][KWp][Cin] fp16 and hands the network over as a small "op
 // program" (salve_resnet_op_t): CONV (+bias, +residual, ReLU), MAXPOOL 3x3/2, AVGPOOL+FC.  The library just runs it.
 //
-// Convolution = implicit GEMM on NHWC bf16 activations:  out[m, n] = sum_k A[m, k] W[n, k],  m = (b, oy, ox),
-// k = (kh, kw, ci).  Block tile 128 x BN x 64, four waves (2 x 2), v_mfma_f32_16x16x32_bf16, the im2col gather of
+// Convolution = implicit GEMM on NHWC fp16 activations:  out[m, n] = sum_k A[m, k] W[n, k],  m = (b, oy, ox),
+// k = (kh, kw, ci).  Block tile 128 x BN x 64, four waves (2 x 2), v_mfma_f32_16x16x32_f16, the im2col gather of
 // A staged global -> registers -> LDS one k-tile ahead of the MFMAs (issue-early / write-late), epilogue through
 // LDS so that the residual read and the output store are 16-byte coalesced.  The 7x7/2 stem runs through the same
 // kernel: input channels are padded to 8 (or 16) and kw to 8 so that one k-tile is one kernel row.
@@ -21,11 +21,11 @@
 
 namespace {
 
-typedef __attribute__((__ext_vector_type__(8))) __bf16 bf16x8;
+typedef __attribute__((__ext_vector_type__(8))) _Float16 act8;  // 8 activations / weights: IEEE half precision
 typedef __attribute__((__ext_vector_type__(4))) float f32x4;
 
 constexpr int BM = 128;
-constexpr int BK = 64;       // one k-tile = 64 bf16 = one 128-byte LDS row = 8 chunks of 16 bytes
+constexpr int BK = 64;       // one k-tile = 64 halves = one 128-byte LDS row = 8 chunks of 16 bytes
 constexpr int CONV_THREADS = 256;
 
 struct ConvArgs {
@@ -43,12 +43,13 @@ struct ConvArgs {
     int Hi2, Wi2, Cin2, stride2, nkt1;
 };
 
-__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // keep NaNs NaN
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// Activations and weights are IEEE half precision (fp16: 11 significand bits; the MFMA rate is that of bf16).  With bf16
+// storage (8 bits) the logits of the 152-layer network missed the 1e-3 parity bound; fp16 meets it with margin.  The
+// conversion saturates at the fp16 range instead of producing infinities.
+__device__ __forceinline__ float act_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t f32_to_act(float f) {
+    f = fminf(fmaxf(f, -65504.f), 65504.f);  // (a NaN stays a NaN through the conversion below)
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
 }
 
 typedef __attribute__((address_space(1))) const void* global_cptr;
@@ -164,28 +165,28 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
         const uint16_t* Bs = As + BM * BK;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ks++) {
-            bf16x8 af[4], bfr[NT];
+            act8 af[4], bfr[NT];
             const int slot = ((ks * 4 + frag_q) ^ frag_sw) * 8;
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                af[i] = *reinterpret_cast<const bf16x8*>(As + (wr * 64 + i * 16 + frag_row) * BK + slot);
+                af[i] = *reinterpret_cast<const act8*>(As + (wr * 64 + i * 16 + frag_row) * BK + slot);
 #pragma unroll
             for (int j = 0; j < NT; j++)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + (wc * WN + j * 16 + frag_row) * BK + slot);
+                bfr[j] = *reinterpret_cast<const act8*>(Bs + (wc * WN + j * 16 + frag_row) * BK + slot);
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < NT; j++)
                     // operands swapped: the accumulator is the TRANSPOSED tile, so a lane owns 4 consecutive output
                     // channels of one output pixel (8 bytes of the NHWC row) instead of 4 pixels of one channel
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();  // everyone is done reading the tile
     }
 #undef ISSUE_TILE
 
     // ---- epilogue: (residual tile ->) LDS, add bias / residual / ReLU in fp32 on the accumulator's own elements,
-    //      round once to bf16, then 16-byte coalesced stores.
+    //      round once to fp16, then 16-byte coalesced stores.
     uint16_t* Cs = smem;
     constexpr int CH_PER_ROW = BN / 8;
     constexpr int C_ITERS = (BM * CH_PER_ROW) / CONV_THREADS;
@@ -212,17 +213,17 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
             float v0 = acc[i][j][0] + bias.x, v1 = acc[i][j][1] + bias.y, v2 = acc[i][j][2] + bias.z, v3 = acc[i][j][3] + bias.w;
             if (p.res) {
                 const uint2 r = *cell;
-                v0 += bf16_to_f32((uint16_t)(r.x & 0xFFFFu));
-                v1 += bf16_to_f32((uint16_t)(r.x >> 16));
-                v2 += bf16_to_f32((uint16_t)(r.y & 0xFFFFu));
-                v3 += bf16_to_f32((uint16_t)(r.y >> 16));
+                v0 += act_to_f32((uint16_t)(r.x & 0xFFFFu));
+                v1 += act_to_f32((uint16_t)(r.x >> 16));
+                v2 += act_to_f32((uint16_t)(r.y & 0xFFFFu));
+                v3 += act_to_f32((uint16_t)(r.y >> 16));
             }
             if (p.relu) {
                 v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
             }
             uint2 o;
-            o.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-            o.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+            o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
+            o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
             *cell = o;
         }
     }
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     }
 }
 
-// 3x3 / stride 2 / pad 1 max-pool on NHWC bf16, 8 channels (16 bytes) per thread.
+// 3x3 / stride 2 / pad 1 max-pool on NHWC fp16, 8 channels (16 bytes) per thread.
 __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B,
                                                       int Hi, int Wi, int C, int Ho, int Wo) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -263,14 +264,14 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                best[2 * k] = fmaxf(best[2 * k], bf16_to_f32((uint16_t)(w[k] & 0xFFFFu)));
-                best[2 * k + 1] = fmaxf(best[2 * k + 1], bf16_to_f32((uint16_t)(w[k] >> 16)));
+                best[2 * k] = fmaxf(best[2 * k], act_to_f32((uint16_t)(w[k] & 0xFFFFu)));
+                best[2 * k + 1] = fmaxf(best[2 * k + 1], act_to_f32((uint16_t)(w[k] >> 16)));
             }
         }
     }
     uint32_t o[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) o[k] = (uint32_t)f32_to_bf16(best[2 * k]) | ((uint32_t)f32_to_bf16(best[2 * k + 1]) << 16);
+    for (int k = 0; k < 4; k++) o[k] = (uint32_t)f32_to_act(best[2 * k]) | ((uint32_t)f32_to_act(best[2 * k + 1]) << 16);
     *reinterpret_cast<uint4*>(out + (((long long)b * Ho + oy) * Wo + ox) * C + ch * 8) = uint4{o[0], o[1], o[2], o[3]};
 }
 
@@ -296,8 +297,8 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const uint16_t* __restr
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                s[2 * e] += bf16_to_f32((uint16_t)(w[e] & 0xFFFFu));
-                s[2 * e + 1] += bf16_to_f32((uint16_t)(w[e] >> 16));
+                s[2 * e] += act_to_f32((uint16_t)(w[e] & 0xFFFFu));
+                s[2 * e + 1] += act_to_f32((uint16_t)(w[e] >> 16));
             }
         }
         for (int k = 0; k < ncls; k++) {
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const uint16_t* __restr
 // A workgroup (4 waves) owns a tile of TH x 16 output pixels of one image:
 //   GEMM 1  t1[halo pixel][MID]   = relu(X[halo pixel][4 MID] . Wa^T + ba), zero outside the image (that IS the 3x3
 //           convolution's zero padding); halo = (TH+2) x 18 pixels, padded to M1 rows; K = 4 MID in k-tiles of 64;
-//           operands staged by global_load_lds exactly as in conv_igemm_kernel; result to LDS (bf16, swizzled rows).
+//           operands staged by global_load_lds exactly as in conv_igemm_kernel; result to LDS (fp16, swizzled rows).
 //   GEMM 2  t2[pixel][MID] = relu(sum over the 9 taps  t1[pixel + tap][MID] . Wb[tap]^T + bb): the A fragments are read
 //           straight out of t1 -- the 16 pixels of a tile row are 16 consecutive halo rows --, Wb streams through LDS.
 //   GEMM 3  Y[pixel][4 MID] = relu(t2 . Wc^T + bc + X[pixel]), 128 output channels at a time, epilogue through LDS with
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const uint16_t* __restr
 struct BottleneckArgs {
     const uint16_t* x;
     uint16_t* y;
-    const uint16_t *wa, *wb, *wc;  // [MID][4 MID], [MID][3][3][MID], [4 MID][MID]  (BatchNorm folded, bf16)
+    const uint16_t *wa, *wb, *wc;  // [MID][4 MID], [MID][3][3][MID], [4 MID][MID]  (BatchNorm folded, fp16)
     const float *ba, *bb, *bc;
     const uint16_t* zeros;
     int B, H, W, tiles_x, tiles_y;
@@ -445,25 +446,25 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const int slot = ((ks * 4 + frag_q) ^ ((frag_row >> 1) & 7)) * 8;
-                bf16x8 af[MT1], bfr[NT1];
+                act8 af[MT1], bfr[NT1];
 #pragma unroll
                 for (int i = 0; i < MT1; i++)
-                    af[i] = *reinterpret_cast<const bf16x8*>(As + ((wm * MT1 + i) * 16 + frag_row) * 64 + slot);
+                    af[i] = *reinterpret_cast<const act8*>(As + ((wm * MT1 + i) * 16 + frag_row) * 64 + slot);
 #pragma unroll
                 for (int j = 0; j < NT1; j++)
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(BsA + ((wn * NT1 + j) * 16 + frag_row) * 64 + slot);
+                    bfr[j] = *reinterpret_cast<const act8*>(BsA + ((wn * NT1 + j) * 16 + frag_row) * 64 + slot);
 #pragma unroll
                 for (int i = 0; i < MT1; i++)
 #pragma unroll
                     for (int j = 0; j < NT1; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");  // everyone is done reading this buffer
         }
 #undef ISSUE_A
         ISSUE_WB(0);  // first Wb stage: lands while t1 is written (its buffer is behind t1)
-        // t1 rows: MID bf16 = MID / 8 chunks of 16 bytes, chunk q of row h stored at slot q ^ swz(h)
+        // t1 rows: MID halves = MID / 8 chunks of 16 bytes, chunk q of row h stored at slot q ^ swz(h)
 #pragma unroll
         for (int i = 0; i < MT1; i++) {
             const int h = (wm * MT1 + i) * 16 + frag_row;
@@ -477,8 +478,8 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 float v0 = fmaxf(acc[i][j][0] + bias.x, 0.f), v1 = fmaxf(acc[i][j][1] + bias.y, 0.f);
                 float v2 = fmaxf(acc[i][j][2] + bias.z, 0.f), v3 = fmaxf(acc[i][j][3] + bias.w, 0.f);
                 uint2 o;
-                o.x = inside ? ((uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16)) : 0u;
-                o.y = inside ? ((uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16)) : 0u;
+                o.x = inside ? ((uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16)) : 0u;
+                o.y = inside ? ((uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16)) : 0u;
                 *reinterpret_cast<uint2*>(T1 + h * MID + (((c0 >> 3) ^ swz) << 3) + (c0 & 7)) = o;
             }
         }
@@ -509,22 +510,22 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
-                    bf16x8 af[RT], bfr[NT2];
+                    act8 af[RT], bfr[NT2];
 #pragma unroll
                     for (int i = 0; i < RT; i++) {
                         const int h = (wr * RT + i + dy) * HC + dx + frag_row;
                         const int swz = MID == 64 ? ((h >> 1) & 7) : (h & 15);
-                        af[i] = *reinterpret_cast<const bf16x8*>(T1 + h * MID + (((kh * 8 + ks * 4 + frag_q) ^ swz) << 3));
+                        af[i] = *reinterpret_cast<const act8*>(T1 + h * MID + (((kh * 8 + ks * 4 + frag_q) ^ swz) << 3));
                     }
                     const int slot = ((ks * 4 + frag_q) ^ ((frag_row >> 1) & 7)) * 8;
 #pragma unroll
                     for (int j = 0; j < NT2; j++)
-                        bfr[j] = *reinterpret_cast<const bf16x8*>(Bst + q * MID * 64 + ((wc * NT2 + j) * 16 + frag_row) * 64 + slot);
+                        bfr[j] = *reinterpret_cast<const act8*>(Bst + q * MID * 64 + ((wc * NT2 + j) * 16 + frag_row) * 64 + slot);
 #pragma unroll
                     for (int i = 0; i < RT; i++)
 #pragma unroll
                         for (int j = 0; j < NT2; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -539,8 +540,8 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const int c0 = (wc * NT2 + j) * 16 + 4 * frag_q;
                 const float4 bias = *reinterpret_cast<const float4*>(p.bb + c0);
                 uint2 o;
-                o.x = (uint32_t)f32_to_bf16(fmaxf(acc[i][j][0] + bias.x, 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(acc[i][j][1] + bias.y, 0.f)) << 16);
-                o.y = (uint32_t)f32_to_bf16(fmaxf(acc[i][j][2] + bias.z, 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(acc[i][j][3] + bias.w, 0.f)) << 16);
+                o.x = (uint32_t)f32_to_act(fmaxf(acc[i][j][0] + bias.x, 0.f)) | ((uint32_t)f32_to_act(fmaxf(acc[i][j][1] + bias.y, 0.f)) << 16);
+                o.y = (uint32_t)f32_to_act(fmaxf(acc[i][j][2] + bias.z, 0.f)) | ((uint32_t)f32_to_act(fmaxf(acc[i][j][3] + bias.w, 0.f)) << 16);
                 *reinterpret_cast<uint2*>(T2 + m * MID + (((c0 >> 3) ^ swz) << 3) + (c0 & 7)) = o;
             }
         }
@@ -580,22 +581,22 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             for (int q = 0; q < KT_MID; q++)
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
-                    bf16x8 af[RT], bfr[4];
+                    act8 af[RT], bfr[4];
 #pragma unroll
                     for (int i = 0; i < RT; i++) {
                         const int m = (wr * RT + i) * 16 + frag_row;
                         const int swz = MID == 64 ? ((m >> 1) & 7) : (m & 15);
-                        af[i] = *reinterpret_cast<const bf16x8*>(T2 + m * MID + (((q * 8 + ks * 4 + frag_q) ^ swz) << 3));
+                        af[i] = *reinterpret_cast<const act8*>(T2 + m * MID + (((q * 8 + ks * 4 + frag_q) ^ swz) << 3));
                     }
                     const int slot = ((ks * 4 + frag_q) ^ ((frag_row >> 1) & 7)) * 8;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        bfr[j] = *reinterpret_cast<const bf16x8*>(BsC + q * 128 * 64 + ((wc * 4 + j) * 16 + frag_row) * 64 + slot);
+                        bfr[j] = *reinterpret_cast<const act8*>(BsC + q * 128 * 64 + ((wc * 4 + j) * 16 + frag_row) * 64 + slot);
 #pragma unroll
                     for (int i = 0; i < RT; i++)
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -606,13 +607,13 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                     const int m = (wr * RT + i) * 16 + frag_row;
                     uint2* cell = reinterpret_cast<uint2*>(Cs + m * LDC + ncol);
                     const uint2 r = *cell;
-                    const float v0 = fmaxf(acc[i][j][0] + bias.x + bf16_to_f32((uint16_t)(r.x & 0xFFFFu)), 0.f);
-                    const float v1 = fmaxf(acc[i][j][1] + bias.y + bf16_to_f32((uint16_t)(r.x >> 16)), 0.f);
-                    const float v2 = fmaxf(acc[i][j][2] + bias.z + bf16_to_f32((uint16_t)(r.y & 0xFFFFu)), 0.f);
-                    const float v3 = fmaxf(acc[i][j][3] + bias.w + bf16_to_f32((uint16_t)(r.y >> 16)), 0.f);
+                    const float v0 = fmaxf(acc[i][j][0] + bias.x + act_to_f32((uint16_t)(r.x & 0xFFFFu)), 0.f);
+                    const float v1 = fmaxf(acc[i][j][1] + bias.y + act_to_f32((uint16_t)(r.x >> 16)), 0.f);
+                    const float v2 = fmaxf(acc[i][j][2] + bias.z + act_to_f32((uint16_t)(r.y & 0xFFFFu)), 0.f);
+                    const float v3 = fmaxf(acc[i][j][3] + bias.w + act_to_f32((uint16_t)(r.y >> 16)), 0.f);
                     uint2 o;
-                    o.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-                    o.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                    o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
+                    o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
                     *cell = o;
                 }
             }
@@ -671,9 +672,9 @@ bool check_op(const salve_resnet_op_t& o) {
 extern "C" {
 
 void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,
-                          const void* weights_bf16, size_t weights_bytes, const float* params_f32, size_t params_bytes,
+                          const void* weights_f16, size_t weights_bytes, const float* params_f32, size_t params_bytes,
                           const int32_t* ktab, size_t ktab_entries) {
-    if (!ops || n_ops <= 0 || !weights_bf16 || !params_f32 || !ktab) {
+    if (!ops || n_ops <= 0 || !weights_f16 || !params_f32 || !ktab) {
         salve_fail("salve_resnet_create: null argument");
         return nullptr;
     }
@@ -727,7 +728,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
         salve_resnet_destroy(h);
         return nullptr;
     }
-    if (hipMemcpy(h->d_weights, weights_bf16, weights_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemcpy(h->d_weights, weights_f16, weights_bytes, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_params, params_f32, params_bytes, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_ktab, ktab, ktab_entries * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(h->d_zeros, 0, 256) != hipSuccess) {

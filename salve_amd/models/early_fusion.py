@@ -77,5 +77,5 @@ class EarlyFusionCEResnet(nn.Module):
         return eng.forward_nhwc(nchw_to_input(xs, eng.in_channels))
 
     def forward_nhwc(self, x: Tensor) -> Tensor:
-        """Fused-pipeline entry: bf16 [B,224,224,Cpad] tiles written by the rasteriser -> fp32 logits."""
+        """Fused-pipeline entry: fp16 [B,224,224,Cpad] tiles written by the rasteriser -> fp32 logits."""
         return self.compiled(x.device).forward_nhwc(x)

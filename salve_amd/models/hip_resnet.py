@@ -57,7 +57,7 @@ class _Builder:
         wp[:, :, :KW, :Cin] = w.permute(0, 2, 3, 1)
         K = KH * KWp * Cinp
         assert K % 64 == 0 and Cout % 64 == 0, (K, Cout)
-        bits = wp.reshape(Cout, K).to(torch.bfloat16).view(torch.int16).numpy().copy()
+        bits = wp.reshape(Cout, K).to(torch.float16).view(torch.int16).numpy().copy()
         q = np.arange(K // 8)
         c8 = q % (Cinp // 8)
         kw = (q // (Cinp // 8)) % KWp
@@ -85,7 +85,7 @@ class _Builder:
         assert w.shape[2:] == (1, 1) and w2.shape[2:] == (1, 1) and Cin % 64 == 0 and Cin2 % 64 == 0 and Cout % 64 == 0
         assert (Hi2 - 1) // stride2 + 1 == Hi and (Wi2 - 1) // stride2 + 1 == Wi
         wcat = torch.cat([w.reshape(Cout, Cin), w2.reshape(Cout, Cin2)], dim=1).float()
-        bits = wcat.to(torch.bfloat16).view(torch.int16).numpy().copy()
+        bits = wcat.to(torch.float16).view(torch.int16).numpy().copy()
         tab = np.zeros((Cin + Cin2) // 8, dtype=np.int32)  # not read by the point-wise kernel
         self.ops.append((OP_CONV, in_buf, out_buf, NO_BUF, Hi, Wi, Cin, Hi, Wi, Cout, 1, 1, 1, 0, 1, 0,
                          self.w_elems, self.p_elems, self.k_elems, in2_buf, Cin2, stride2, Hi2, Wi2, 0))
@@ -118,7 +118,7 @@ def _bn(sd: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Tensor]:
 
 def build_program(state_dict: Dict[str, torch.Tensor], num_layers: int, in_hw: Tuple[int, int] = (224, 224)):
     """state_dict with the reference's keys (conv1.weight, fc.*, resnet.*; an optional `module.` prefix from
-    DataParallel is stripped) -> (ops array, bf16 weight bits, fp32 params, ktab, padded input channels)."""
+    DataParallel is stripped) -> (ops array, fp16 weight bits, fp32 params, ktab, padded input channels)."""
     sd = {(k[len("module."):] if k.startswith("module.") else k): v.detach().cpu() for k, v in state_dict.items()}
     kind, blocks = RESNET_SPECS[num_layers]
     b = _Builder()
@@ -196,8 +196,8 @@ class HipResNet:
             pass
 
     def forward_nhwc(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-        """x: bf16 [B, 224, 224, in_channels] on the device -> fp32 logits [B, num_classes]."""
-        assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] == self.in_channels, (x.dtype, x.shape)
+        """x: fp16 [B, 224, 224, in_channels] on the device -> fp32 logits [B, num_classes]."""
+        assert x.dtype == torch.float16 and x.is_contiguous() and x.shape[-1] == self.in_channels, (x.dtype, x.shape)
         B = int(x.shape[0])
         need = self.lib.salve_resnet_workspace_bytes(self.handle, B)
         if self._ws is None or self._ws.numel() < need:
@@ -213,9 +213,9 @@ class HipResNet:
 
 
 def nchw_to_input(xs: List[torch.Tensor], in_channels: int) -> torch.Tensor:
-    """[B,3,H,W] fp32 tensors (the reference's x1..x6) -> one bf16 NHWC tensor padded to in_channels."""
+    """[B,3,H,W] fp32 tensors (the reference's x1..x6) -> one fp16 NHWC tensor padded to in_channels."""
     x = torch.cat(xs, dim=1)
     B, C, H, W = x.shape
-    out = torch.zeros((B, H, W, in_channels), dtype=torch.bfloat16, device=x.device)
-    out[..., :C] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    out = torch.zeros((B, H, W, in_channels), dtype=torch.float16, device=x.device)
+    out[..., :C] = x.permute(0, 2, 3, 1).to(torch.float16)
     return out

@@ -57,8 +57,8 @@ class RenderVerifyPipeline:
         # kernel.  (Requires the library to be built without SLP-packed fp32: DESIGN.md section 8.)
         self.nbuf = 2 if overlap else 1
         self.bevs = [torch.empty((chunk * S, Hb, Wb), dtype=torch.int32, device=self.device) for _ in range(self.nbuf)]
-        # tiles: bf16 NHWC, pad channels (never written) stay zero
-        self.tile_bufs = [torch.zeros((chunk, self.ras.crop, self.ras.crop, self.engine.in_channels), dtype=torch.bfloat16,
+        # tiles: fp16 NHWC, pad channels (never written) stay zero
+        self.tile_bufs = [torch.zeros((chunk, self.ras.crop, self.ras.crop, self.engine.in_channels), dtype=torch.float16,
                                       device=self.device) for _ in range(self.nbuf)]
         self.bev, self.tiles = self.bevs[0], self.tile_bufs[0]
         self.render_stream = torch.cuda.Stream(self.device) if overlap else None
@@ -136,8 +136,8 @@ class RenderVerifyPipeline:
         if timers is not None:
             e1.record()
             timers.append((e0, e1, n * S))
-        self.ras.tiles(bev, prepared["jobs1"][lo * S * jb:], n * S, tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
-        self.ras.tiles(self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
+        self.ras.tiles(bev, prepared["jobs1"][lo * S * jb:], n * S, tiles, _lib.TILE_F16_NHWC, self.engine.in_channels)
+        self.ras.tiles(self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, tiles, _lib.TILE_F16_NHWC, self.engine.in_channels)
 
     def _render_chunk(self, prepared, lo: int, n: int, buf: int, timers=None) -> None:
         S = len(self.surfaces)
@@ -154,8 +154,8 @@ class RenderVerifyPipeline:
             timers.append((e0, e1, n * S))
         else:
             self.ras.render(self.pano_rgb, self.pano_depth, rows, n * S, out_bev=bev)
-        self.ras.tiles(bev, prepared["jobs1"][lo * S * jb:], n * S, tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
-        self.ras.tiles(self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, tiles, _lib.TILE_BF16_NHWC, self.engine.in_channels)
+        self.ras.tiles(bev, prepared["jobs1"][lo * S * jb:], n * S, tiles, _lib.TILE_F16_NHWC, self.engine.in_channels)
+        self.ras.tiles(self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, tiles, _lib.TILE_F16_NHWC, self.engine.in_channels)
 
     def score(self, prepared, out: Optional[torch.Tensor] = None, timers=None) -> torch.Tensor:
         """Render + verify every hypothesis of a prepared shard.  Returns fp32 logits [N, num_classes].

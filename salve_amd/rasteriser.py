@@ -222,7 +222,7 @@ class BevRasteriser:
         return torch.from_numpy(j.view(np.uint8)).to(self.device)
 
     def tiles(self, bev: torch.Tensor, jobs_dev: torch.Tensor, n_jobs: int, out: torch.Tensor, fmt: int, out_c: int) -> torch.Tensor:
-        """Resize -> crop -> normalise into `out` (float32 NCHW or bf16 NHWC, see include/salve_hip.h)."""
+        """Resize -> crop -> normalise into `out` (float32 NCHW or fp16 NHWC, see include/salve_hip.h)."""
         Hb, Wb = self.bev_hw
         st = self.lib.salve_bev_tiles(
             ctypes.c_void_p(bev.data_ptr()), Hb, Wb, ctypes.c_void_p(jobs_dev.data_ptr()), n_jobs,

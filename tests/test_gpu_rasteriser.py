@@ -116,14 +116,14 @@ def test_tiles_match_oracle(setup):
     out = torch.zeros((1, 6, 224, 224), dtype=torch.float32, device=ras.device)
     jobs = ras.upload_tile_jobs([0, 1], [0, 0], [0, 3])
     ras.tiles(bev, jobs, 2, out, _lib.TILE_F32_NCHW, 6)
-    out_bf = torch.zeros((1, 224, 224, 8), dtype=torch.bfloat16, device=ras.device)
-    ras.tiles(bev, jobs, 2, out_bf, _lib.TILE_BF16_NHWC, 8)
+    out_bf = torch.zeros((1, 224, 224, 8), dtype=torch.float16, device=ras.device)
+    ras.tiles(bev, jobs, 2, out_bf, _lib.TILE_F16_NHWC, 8)
     torch.cuda.synchronize()
     bev_u8 = ras.export_u8(bev).cpu().numpy()
     exp = np.concatenate([bo.tile_from_bev(bev_u8[0]), bo.tile_from_bev(bev_u8[1])], 0)
     assert np.array_equal(out.cpu().numpy()[0], exp)  # integer taps + float32 LUT: exact
     got_bf = out_bf.float().cpu().numpy()[0].transpose(2, 0, 1)
-    assert np.array_equal(got_bf[:6], torch.from_numpy(exp).bfloat16().float().numpy())
+    assert np.array_equal(got_bf[:6], torch.from_numpy(exp).half().float().numpy())
     assert not got_bf[6:].any()
 
 

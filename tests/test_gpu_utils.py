@@ -66,7 +66,7 @@ def test_interp_dense_grid_from_sparse():
 
 
 def test_config5_large_panos_two_surfaces_resnet152():
-    """2048x1024 panoramas, floor + ceiling, ResNet-152 12-channel early fusion (BASELINE config 5, bf16)."""
+    """2048x1024 panoramas, floor + ceiling, ResNet-152 12-channel early fusion (BASELINE config 5, fp16)."""
     from salve_amd.models.early_fusion import EarlyFusionCEResnet
     from salve_amd.pipeline import RenderVerifyPipeline
     from tests.test_gpu_verifier import randomise_bn
@@ -92,9 +92,9 @@ def test_config5_large_panos_two_surfaces_resnet152():
         tiles += [bo.tile_from_bev(r1["bev"]), bo.tile_from_bev(r2["bev"])]
     got_tiles = pipe.tiles[0].float().cpu().permute(2, 0, 1)
     exp_tiles = torch.from_numpy(np.concatenate(tiles, 0))
-    assert torch.equal(got_tiles[:12], exp_tiles.bfloat16().float()) and not got_tiles[12:].any()
+    assert torch.equal(got_tiles[:12], exp_tiles.half().float()) and not got_tiles[12:].any()
     with torch.no_grad():
-        ref = ro.forward(model.state_dict(), 152, [t[None].bfloat16().float() for t in exp_tiles.split(3)])
+        ref = ro.forward(model.state_dict(), 152, [t[None].half().float() for t in exp_tiles.split(3)])
     err = float((logits[:1] - ref).abs().max())
     print(f"config 5: logits {logits[0].tolist()} oracle {ref[0].tolist()} err {err:.2e}")
     assert err < 3e-2 * max(1.0, float(ref.abs().max()))

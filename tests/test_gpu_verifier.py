@@ -1,4 +1,4 @@
-"""GPU parity of the HIP ResNet verifier (bf16 MFMA) against the fp32 CPU oracle, through the C ABI."""
+"""GPU parity of the HIP ResNet verifier (fp16 MFMA) against the fp32 CPU oracle, through the C ABI."""
 
 import ctypes
 from types import SimpleNamespace
@@ -30,7 +30,7 @@ def randomise_bn(model, seed=0):
 
 
 def run_single_conv(w, b, x_nhwc, stride, pad, relu, res=None, kw_pad=0):
-    """One CONV op through salve_resnet_create / salve_resnet_forward; returns the bf16 NHWC output as fp32."""
+    """One CONV op through salve_resnet_create / salve_resnet_forward; returns the fp16 NHWC output as fp32."""
     lib = _lib.load()
     bld = hip_resnet._Builder()
     B, Hi, Wi, Cp = x_nhwc.shape
@@ -50,7 +50,7 @@ def run_single_conv(w, b, x_nhwc, stride, pad, relu, res=None, kw_pad=0):
     Cout = w.shape[0]
     per_buf = (need - 256) // (2 if res is not None else 1) // 2
     base_off = (-ws.data_ptr()) % 256
-    view = ws[base_off:].view(torch.bfloat16)
+    view = ws[base_off:].view(torch.float16)
     if res is not None:
         view[per_buf:per_buf + res.numel()] = res.reshape(-1).to(DEV)
         ops1 = ops[:1]
@@ -85,16 +85,16 @@ def test_conv_matches_torch(case):
     b = torch.randn(case["cout"], generator=g) * 0.1
     x = torch.randn(B, case["cin"], case["hw"], case["hw"], generator=g)
     cp = hip_resnet.pad_channels(case["cin"])
-    x_nhwc = torch.zeros(B, case["hw"], case["hw"], cp, dtype=torch.bfloat16)
-    x_nhwc[..., : case["cin"]] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    x_nhwc = torch.zeros(B, case["hw"], case["hw"], cp, dtype=torch.float16)
+    x_nhwc[..., : case["cin"]] = x.permute(0, 2, 3, 1).to(torch.float16)
     got = run_single_conv(w, b, x_nhwc, case["s"], case["p"], case["relu"], kw_pad=case.get("kw_pad", 0))
     xr = x_nhwc[..., : case["cin"]].float().permute(0, 3, 1, 2)
-    ref = torch.nn.functional.conv2d(xr, w.to(torch.bfloat16).float(), b, case["s"], case["p"])
+    ref = torch.nn.functional.conv2d(xr, w.to(torch.float16).float(), b, case["s"], case["p"])
     if case["relu"]:
         ref = ref.relu()
     ref = ref.permute(0, 2, 3, 1)
     err = (got - ref).abs()
-    tol = 2e-2 * ref.abs().clamp(min=0.5)  # two bf16 ulps of the output
+    tol = 3e-3 * ref.abs().clamp(min=0.5)  # three fp16 ulps of the output (fp32 accumulation, one rounding at the store)
     assert (err <= tol).all(), f"max err {err.max()} at |ref| {ref.abs().max()}"
 
 
@@ -104,16 +104,15 @@ def test_conv_matches_torch(case):
     (18, ["layout"], 3),
 ])
 def test_logits_match_oracle(num_layers, modalities, batch):
-    """Tolerance: bf16 activations/weights with fp32 accumulation.  north_star asks 1e-3 on logits for the
-    fp path; bf16 storage (8 significand bits) cannot reach that, so the bound here is 3e-2 of the logit scale and
-    the measured error is printed."""
+    """north_star asks 1e-3 on the logits.  Activations and weights are fp16 (11 significand bits), accumulation fp32:
+    the bound here is 1e-3 of the logit scale (>= 1), and the measured error is printed."""
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(num_layers, False, 2, SimpleNamespace(modalities=modalities))
     randomise_bn(model)
     model.eval()
     n = len(modalities) * 2
     xs = [torch.randn(batch, 3, 224, 224) for _ in range(n)]
-    xs_b = [x.to(torch.bfloat16).float() for x in xs]  # the network input is bf16 on the GPU side
+    xs_b = [x.to(torch.float16).float() for x in xs]  # the network input is fp16 on the GPU side
     with torch.no_grad():
         ref = ro.forward(model.state_dict(), num_layers, xs_b)
         pad = xs + [None] * (6 - n)
@@ -121,8 +120,8 @@ def test_logits_match_oracle(num_layers, modalities, batch):
     scale = max(1.0, float(ref.abs().max()))
     err = float((got - ref).abs().max())
     print(f"resnet{num_layers}: logits scale {scale:.3f}, max abs err {err:.4f}")
-    assert err <= 3e-2 * scale
-    assert (got.argmax(1) == ref.argmax(1)).all() or err < 1e-2
+    assert err <= 1e-3 * scale
+    assert (got.argmax(1) == ref.argmax(1)).all() or err < 1e-3
 
 
 @pytest.mark.parametrize("stride,hw,cx,mid,cout", [(1, 56, 64, 64, 256), (2, 28, 256, 128, 512)])
@@ -139,7 +138,7 @@ def test_conv_with_projection_shortcut_as_second_source(stride, hw, cx, mid, cou
     w2 = torch.randn(cout, cx, 1, 1, generator=g) * (1.0 / cx) ** 0.5
     b2 = torch.randn(cout, generator=g) * 0.1
     x = torch.randn(B, cx, hw, hw, generator=g)
-    x_nhwc = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+    x_nhwc = x.permute(0, 2, 3, 1).to(torch.float16).contiguous()
     bld = hip_resnet._Builder()
     Ho, Wo = bld.conv(wb3, bb3, hip_resnet.NET_INPUT, 0, hip_resnet.NO_BUF, hw, hw, stride, 1, True)
     bld.conv1x1_with_shortcut(w, b, 0, 1, Ho, Wo, w2, b2, hip_resnet.NET_INPUT, hw, hw, stride)
@@ -155,26 +154,26 @@ def test_conv_with_projection_shortcut_as_second_source(stride, hw, cx, mid, cou
     st = lib.salve_resnet_forward(h, ctypes.c_void_p(xd.data_ptr()), B, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), None)
     torch.cuda.synchronize()
     assert st == 0, lib.salve_last_error()
-    per_buf = (need - 256) // 2 // 2                    # two buffers of bf16 elements
-    view = ws[(-ws.data_ptr()) % 256:].view(torch.bfloat16)
+    per_buf = (need - 256) // 2 // 2                    # two buffers of 16-bit elements
+    view = ws[(-ws.data_ptr()) % 256:].view(torch.float16)
     got = view[per_buf: per_buf + B * Ho * Wo * cout].float().cpu().reshape(B, Ho, Wo, cout)
     lib.salve_resnet_destroy(h)
     xr = x_nhwc.float().permute(0, 3, 1, 2)
-    t2 = torch.nn.functional.conv2d(xr, wb3.to(torch.bfloat16).float(), bb3, stride, 1).relu().to(torch.bfloat16).float()
-    ref = (torch.nn.functional.conv2d(t2, w.to(torch.bfloat16).float(), b) +
-           torch.nn.functional.conv2d(xr, w2.to(torch.bfloat16).float(), b2, stride)).relu().permute(0, 2, 3, 1)
+    t2 = torch.nn.functional.conv2d(xr, wb3.to(torch.float16).float(), bb3, stride, 1).relu().to(torch.float16).float()
+    ref = (torch.nn.functional.conv2d(t2, w.to(torch.float16).float(), b) +
+           torch.nn.functional.conv2d(xr, w2.to(torch.float16).float(), b2, stride)).relu().permute(0, 2, 3, 1)
     err = (got - ref).abs()
-    assert (err <= 2e-2 * ref.abs().clamp(min=0.5)).all(), f"max err {err.max()}"
+    assert (err <= 3e-3 * ref.abs().clamp(min=0.5)).all(), f"max err {err.max()}"
 
 
 def test_fused_bottleneck_is_bit_identical_to_three_kernels(monkeypatch):
-    """The fused bottleneck kernel (resnet.hip: bottleneck_kernel) keeps t1 / t2 in LDS but rounds them to bf16 and
+    """The fused bottleneck kernel (resnet.hip: bottleneck_kernel) keeps t1 / t2 in LDS but rounds them to fp16 and
     accumulates in the same k order as the three separate convolutions: the logits must agree bit for bit."""
     torch.manual_seed(5)
     model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"]))
     randomise_bn(model, seed=5)
     model.eval()
-    x = torch.randn(3, 224, 224, 8).to(torch.bfloat16).to(DEV)
+    x = torch.randn(3, 224, 224, 8).to(torch.float16).to(DEV)
     x[..., 6:] = 0
     outs = []
     for fuse in ("1", "0"):

@@ -13,7 +13,7 @@ model = EarlyFusionCEResnet(layers, False, 2, SimpleNamespace(modalities=mods)).
 eng = model.compiled(dev)
 flop = {50: 8.41e9, 152: 23.73e9, 18: 3.6e9}[layers]
 for B in ((32, 64, 128, 256, 512) if len(sys.argv) < 3 else tuple(int(v) for v in sys.argv[2].split(","))):
-    x = torch.randn(B, 224, 224, eng.in_channels, device=dev).to(torch.bfloat16)
+    x = torch.randn(B, 224, 224, eng.in_channels, device=dev).to(torch.float16)
     for _ in range(2):
         eng.forward_nhwc(x)
     torch.cuda.synchronize()

@@ -37,7 +37,7 @@ if mode in ("resnet", "resnet_stray", "resnet_bisect"):
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
     eng = model.compiled(dev)
-    x = torch.randn(64, 224, 224, 8, device=dev).to(torch.bfloat16)
+    x = torch.randn(64, 224, 224, 8, device=dev).to(torch.float16)
     y0 = eng.forward_nhwc(x).clone(); torch.cuda.synchronize()
     for rep in range(6 if mode == "resnet" else 0):
         with torch.cuda.stream(side):
@@ -92,7 +92,7 @@ if mode.startswith("op_"):
     h = ctypes.c_void_p(lib.salve_resnet_create(0, cin, ops.ctypes.data_as(ctypes.c_void_p), len(ops), wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
                                                 pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
     ws = torch.zeros(lib.salve_resnet_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
-    xin = torch.randn(B, hw, hw, cin, device=dev).to(torch.bfloat16)
+    xin = torch.randn(B, hw, hw, cin, device=dev).to(torch.float16)
     logits = torch.zeros(B, 2, device=dev)
     for rep in range(6):
         with torch.cuda.stream(side):

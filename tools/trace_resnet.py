@@ -10,7 +10,7 @@ torch.manual_seed(0)
 model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
 eng = model.compiled(dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-x = torch.randn(B, 224, 224, eng.in_channels, device=dev).to(torch.bfloat16)
+x = torch.randn(B, 224, 224, eng.in_channels, device=dev).to(torch.float16)
 for _ in range(3):
     eng.forward_nhwc(x)
 torch.cuda.synchronize()
