@@ -78,8 +78,8 @@ def test_unfused_test_epoch_writes_prediction_files(tmp_path):
         xs = [torch.from_numpy(bo.tile_from_bev(image_io.read_rgb(p)))[None] for p in (c1, c2, f1, f2)]
         logits = ro.forward(sd, 18, xs)
         probs = torch.softmax(logits, 1)[0]
-        assert int(torch.argmax(probs)) == d["y_hat"][j] or abs(float(probs[0] - probs[1])) < 2e-2
-        assert abs(float(probs[d["y_hat"][j]]) - d["y_hat_probs"][j]) < 2e-2
+        assert int(torch.argmax(probs)) == d["y_hat"][j] or abs(float(probs[0] - probs[1])) < 5e-3
+        assert abs(float(probs[d["y_hat"][j]]) - d["y_hat_probs"][j]) < 5e-3
     assert set(metrics) == {"split", "checkpoint_file_path", "average_accuracy", "class_accuracies", "precision", "recall", "mean_accuracy"}
 
 

@@ -97,4 +97,4 @@ def test_config5_large_panos_two_surfaces_resnet152():
         ref = ro.forward(model.state_dict(), 152, [t[None].half().float() for t in exp_tiles.split(3)])
     err = float((logits[:1] - ref).abs().max())
     print(f"config 5: logits {logits[0].tolist()} oracle {ref[0].tolist()} err {err:.2e}")
-    assert err < 3e-2 * max(1.0, float(ref.abs().max()))
+    assert err < 1e-3 * max(1.0, float(ref.abs().max()))  # north_star: logits within 1e-3
