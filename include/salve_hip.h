@@ -34,7 +34,7 @@ typedef enum {
     SALVE_ERR_WORKSPACE = -4
 } salve_status_t;
 
-#define SALVE_HIP_ABI_VERSION 1
+#define SALVE_HIP_ABI_VERSION 2  /* 2: salve_resnet_op_t carries a second source (in2_buf ...); fp16 activations; salve_resize_rgb_u8 */
 
 /* Library / ABI version (SALVE_HIP_ABI_VERSION). */
 int salve_hip_version(void);
