@@ -1,6 +1,10 @@
 """Benchmark of the SALVe hot path: alignment hypotheses / second (render + verify) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU under torch.distributed.run (RCCL).  When the script is started WITHOUT a launcher
+(`python bench.py --gpus 8`), it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself as a
+child process -- before anything touches the GPU -- and relays the child's JSON line and exit code.
 
 A step = one pass of the fused render+verify path over the rank's shard of the hypothesis table
 (BASELINE.json configs[2]: 4096 hypotheses over 64 synthetic 1024x512 panoramas, rasteriser + ResNet-50 fp16,
@@ -12,6 +16,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -26,44 +32,101 @@ import torch
 # algorithmic bytes of one render at 1024x512 -> 501x501
 PANO_H, PANO_W, CROP = 512, 1024, 80
 BYTES_PER_RENDER = (PANO_H - 2 * CROP) * PANO_W * (3 + 2) + 501 * 501 * 3  # RGB u8 + depth u16 read, BEV u8 written
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# HBM bytes of one bev_densify_kernel launch of 512 renders from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate
-# passes, KiB units; profiles/r01_pmc_traffic.md).  The kernel reads 4 B / lane, for which FETCH_SIZE is uncalibrated:
-# the read side is taken as counted (lower bound).
-DENSIFY_TRAFFIC_BYTES_PER_RENDER = (472007 + 937658) * 1024 / 512  # measured on launches of 512 renders; one workgroup per render
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0      # same guide: dense fp16 / bf16 MFMA peak
+GFLOP_PER_SAMPLE = {50: 8.410, 152: 23.259, 18: 3.6}  # SURVEY 8d (2 x MAC, 6 input channels); tests/test_oracle_structure.py pins them
+# HBM bytes per render of the WHOLE rasteriser (key-image clear + both scatter passes + densify) from the PMC counters
+# (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes): see RASTERISER_TRAFFIC_SOURCE.  The narrow (4 B / lane) loads are
+# uncalibrated for FETCH_SIZE, so the read side is a lower bound.
+RASTERISER_TRAFFIC_BYTES_PER_RENDER = 8.7e6
+RASTERISER_TRAFFIC_SOURCE = "profiles/r01_pmc_traffic.md"
 
 
-def cpu_baseline(n_hyp: int, procs: int):
-    """The oracle's reference-faithful path (scipy griddata + torch-CPU ResNet-50 fp32) on the host cores,
-    `procs` worker processes (the reference's own parallelism is a multiprocessing.Pool,
-    scripts/render_dataset_bev.py:111-113), on a bounded sample of the same workload."""
+def _cores() -> int:
+    """Physical cores this process may use (the box's share), for the CPU baseline."""
+    try:
+        import psutil
+
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        phys = os.cpu_count() or 1
+    try:
+        phys = min(phys, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return max(1, int(phys))
+
+
+def _cpu_render_pair(i: int):
+    """One hypothesis of BASELINE config 1 on the CPU: both renders of the pair (the reference re-renders the identity
+    pano for every hypothesis, bev_rendering_utils.py:453-455) with the oracle in its reference-faithful scipy mode."""
+    torch.set_num_threads(1)
+    from oracle import bev_oracle as bo
+    from salve_amd import synthetic
+
+    hyp = synthetic.make_hypotheses(16, 1, seed=0)
+    rgb, depth = synthetic.make_pano(0)
+    r1, r2 = bo.render_bev_pair(rgb, depth, rgb, depth, hyp.R[i], hyp.t[i], "floor", mode="scipy")
+    if r1 is None or r2 is None:
+        return None
+    return np.concatenate([bo.tile_from_bev(r1["bev"]), bo.tile_from_bev(r2["bev"])], 0)
+
+
+def cpu_baseline():
+    """BASELINE.json configs[0], literally: ONE 1024x512 synthetic panorama + depth, 16 hypotheses, CPU rasteriser (the
+    oracle's scipy mode = the reference's own call sequence) in a multiprocessing.Pool of `cores` workers (the reference's
+    parallelism, scripts/render_dataset_bev.py:111-113; its default is 15 processes) followed by torch-CPU ResNet-50 fp32 on
+    the 16 tile pairs with `cores` threads (scripts/test.py runs batch 64).  Also the single-process per-render latency."""
     import multiprocessing as mp
 
-    t0 = time.time()
-    with mp.get_context("fork").Pool(procs) as pool:
-        pool.map(_cpu_one, list(range(n_hyp)))
-    dt = time.time() - t0
-    return n_hyp / dt, dt
-
-
-def _cpu_one(i: int) -> int:
-    torch.set_num_threads(1)
     from oracle import bev_oracle as bo
     from oracle import resnet_oracle as ro
     from salve_amd import synthetic
     from salve_amd.models.early_fusion import EarlyFusionCEResnet
 
-    hyp = synthetic.make_hypotheses(64, 64, seed=0)
-    p1, p2 = synthetic.make_pano(int(hyp.i1[i])), synthetic.make_pano(int(hyp.i2[i]))
-    r1, r2 = bo.render_bev_pair(p1[0], p1[1], p2[0], p2[1], hyp.R[i], hyp.t[i], "floor", mode="scipy")
+    cores = _cores()
+    n_hyp = 16
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(min(cores, n_hyp)) as pool:
+        tiles = pool.map(_cpu_render_pair, list(range(n_hyp)))
+    t_render = time.perf_counter() - t0
+    # single-process per-render latency (SURVEY 8d i)
+    hyp = synthetic.make_hypotheses(16, 1, seed=0)
+    rgb, depth = synthetic.make_pano(0)
+    a = bo.xyzrgb_from_arrays(depth, rgb, bo.floor_ceiling_z_range("floor"))
+    a, _ = bo.pose_pair(a, a[:1], hyp.R[0], hyp.t[0])
+    t1 = time.perf_counter()
+    bo.render_bev_image(a, mode="scipy")
+    t_single = time.perf_counter() - t1
     torch.manual_seed(0)
-    model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"]))
-    if r1 is not None:
-        x1 = torch.from_numpy(bo.tile_from_bev(r1["bev"]))[None]
-        x2 = torch.from_numpy(bo.tile_from_bev(r2["bev"]))[None]
-        with torch.no_grad():
-            ro.forward(model.state_dict(), 50, [x1, x2])
-    return i
+    model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    kept = [t for t in tiles if t is not None]
+    x = torch.from_numpy(np.stack(kept))
+    torch.set_num_threads(cores)
+    t2 = time.perf_counter()
+    with torch.no_grad():
+        ro.forward(model.state_dict(), 50, [x[:, :3], x[:, 3:]])
+    t_verify = time.perf_counter() - t2
+    total = t_render + t_verify
+    return {"value": round(n_hyp / total, 4), "unit": "hypotheses/s", "cores": cores, "kind": "port",
+            "sample": f"BASELINE config 1: 1 synthetic 1024x512 panorama, 16 hypotheses = 32 renders (oracle, scipy mode) in a pool of "
+                      f"{min(cores, n_hyp)} processes {t_render:.1f} s + ResNet-50 fp32 torch-CPU batch {len(kept)} on {cores} threads {t_verify:.1f} s; "
+                      f"single-process render latency {t_single:.2f} s",
+            "render_s": round(t_render, 3), "verify_s": round(t_verify, 3), "single_render_s": round(t_single, 3)}
+
+
+def _self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run as a CHILD process (this
+    process has not touched the GPU and never will) and relay its output and exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
 
 def main() -> None:
@@ -77,14 +140,17 @@ def main() -> None:
     ap.add_argument("--no-overlap", action="store_true", help="render and verify on one HIP stream")
     ap.add_argument("--streams", type=int, default=3, help="2: rasteriser | verifier; 3: scatter | densify | verifier")
     ap.add_argument("--layers", type=int, default=50)
+    ap.add_argument("--scene", default="box", help="synthetic scene: box (SURVEY 8d) | cluttered (occluding boxes + door opening)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(_self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -99,10 +165,11 @@ def main() -> None:
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(args.layers, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
     pipe = RenderVerifyPipeline(model, dev, pano_hw=(PANO_H, PANO_W), chunk=args.chunk, overlap=not args.no_overlap, streams=args.streams)
-    panos = [synthetic.make_pano(i, PANO_H, PANO_W) for i in range(args.panos)]
+    panos = [synthetic.make_pano(i, PANO_H, PANO_W, scene=args.scene) for i in range(args.panos)]
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     # weak scaling: every rank scores its own block of `hyps` hypotheses out of a table of world * hyps
-    table = synthetic.make_hypotheses(args.hyps * world, args.panos, seed=0).shard(rank, world)
+    n_total = args.hyps * world
+    table = synthetic.make_hypotheses(n_total, args.panos, seed=0).shard(rank, world)
     prepared = pipe.prepare(table)
     logits = torch.empty((len(table), 2), dtype=torch.float32, device=dev)
 
@@ -114,50 +181,54 @@ def main() -> None:
 
     for _ in range(args.warmup):
         pipe.score(prepared, out=logits)
-        gather_logits(logits, world)
-    stream = torch.cuda.current_stream(dev)
-    ev = []  # (start, end, renders) of every bev_densify_kernel launch of the timed region
+        gather_logits(logits, world, total=n_total)
+    ev, vev = [], []  # HIP events around every rasteriser stage / verifier forward of the timed region, on their own streams
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        pipe.score(prepared, out=logits, timers=ev)
-        allg = gather_logits(logits, world)
+        pipe.score(prepared, out=logits, timers=ev, vtimers=vev)
+        allg = gather_logits(logits, world, total=n_total)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    pipe.check("bench.py")            # no star walk failed, no activation left the fp16 range
+    assert allg.shape[0] == n_total and bool(torch.isfinite(allg).all())
 
     if rank == 0:
-        n_total = args.hyps * world
         value = n_total * args.steps / dt
-        # dominant kernel: bev_densify_kernel, one launch = `chunk` renders; HIP events on the launch stream bracket every
-        # launch of the timed region (with the two-stream default they include the slow-down from the verifier's kernels
-        # sharing the CUs, exactly as the rocprofv3 kernel trace of the same command does)
-        full = [(a.elapsed_time(b), r) for a, b, r in ev if r == min(args.chunk, len(table))]
-        dens_ms = float(np.mean([t for t, _ in full]))
-        renders = full[0][1]
-        achieved = renders * BYTES_PER_RENDER / (dens_ms * 1e-3) / 1e9
+        full_n = min(args.chunk, len(table))
+        mean_ms = lambda tag: float(np.mean([a.elapsed_time(b) for a, b, r, t in ev if t == tag and r == full_n]))
+        scat_ms, dens_ms = mean_ms("scatter"), mean_ms("densify")
+        ras_ms = scat_ms + dens_ms
+        achieved = full_n * BYTES_PER_RENDER / (ras_ms * 1e-3) / 1e9
+        vfull = [(a.elapsed_time(b), r) for a, b, r in vev if r == full_n]
+        ver_ms = float(np.mean([t for t, _ in vfull]))
+        tflops = full_n * GFLOP_PER_SAMPLE[args.layers] / ver_ms  # GFLOP / ms = TFLOP/s
         out = {
             "metric": "alignment hypotheses/sec (render+verify)", "value": round(value, 2), "unit": "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": f"{args.hyps} hypotheses/GPU over {args.panos} synthetic 1024x512 panoramas, floor surface, "
+            "config": {"workload": f"{args.hyps} hypotheses/GPU over {args.panos} synthetic 1024x512 panoramas ({args.scene} scene), floor surface, "
                                    f"HIP BEV rasteriser + ResNet-{args.layers} (6-ch early fusion) fp16 MFMA verifier",
                        "hypotheses_per_gpu": args.hyps, "panos": args.panos, "renders_per_hypothesis": 1,
                        "cached_identity_renders": args.panos, "chunk": args.chunk, "parallelism": f"hypothesis-shard x{world}"},
-            "roofline": {"kernel": "bev_densify_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": int(DENSIFY_TRAFFIC_BYTES_PER_RENDER * renders),
-                         "launch_ms": round(dens_ms, 3), "launches_timed": len(full), "renders_per_launch": renders, "algorithmic_bytes_per_render": BYTES_PER_RENDER},
+            # the rasteriser as a whole (key-image clear + two scatter passes + densify): SURVEY 8d's 2.555 MB per render x the
+            # renders of one launch / the summed average durations of those launches (HIP events on the launching streams)
+            "roofline": {"kernel": "rasteriser: key-image clear + bev_scatter_kernel x2 + bev_densify_kernel", "bound": "hbm",
+                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": int(RASTERISER_TRAFFIC_BYTES_PER_RENDER * full_n), "traffic_source": RASTERISER_TRAFFIC_SOURCE,
+                         "launch_ms": round(ras_ms, 3), "scatter_ms": round(scat_ms, 3), "densify_ms": round(dens_ms, 3),
+                         "launches_timed": len(vfull), "renders_per_launch": full_n, "algorithmic_bytes_per_render": BYTES_PER_RENDER},
+            "roofline_verifier": {"kernel": "conv_igemm / bottleneck kernels of one ResNet forward", "bound": "mfma",
+                                  "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tflops / MFMA_PEAK_TFLOPS, 5), "launch_ms": round(ver_ms, 3),
+                                  "samples_per_launch": full_n, "gflop_per_sample": GFLOP_PER_SAMPLE[args.layers], "traffic": None},
         }
         if world == 1 and not args.no_cpu_baseline:
-            procs = min(os.cpu_count() or 1, 8)
-            v, secs = cpu_baseline(6 * procs, procs)
-            out["cpu_baseline"] = {"value": round(v, 4), "unit": "hypotheses/s", "cores": procs, "kind": "port",
-                                   "sample": f"{6 * procs} hypotheses of the same table (2 renders + ResNet-50 fp32 each), oracle scipy mode, "
-                                             f"{procs} processes, {secs:.1f} s"}
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

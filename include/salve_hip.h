@@ -34,7 +34,14 @@ typedef enum {
     SALVE_ERR_WORKSPACE = -4
 } salve_status_t;
 
-#define SALVE_HIP_ABI_VERSION 2  /* 2: salve_resnet_op_t carries a second source (in2_buf ...); fp16 activations; salve_resize_rgb_u8 */
+#define SALVE_HIP_ABI_VERSION 3  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter */
+
+/* Device status word: an optional device int32 the caller zeroes once and passes to the launches below.  Kernels OR bits
+ * into it when something went wrong that an int return value cannot report (the launch is asynchronous); the caller
+ * reads it back at a point where it synchronises anyway.  0 = every launch since the last reset was sound. */
+#define SALVE_STATUS_WALK_FAILED 1 /* bev_densify: a Delaunay star did not close -- that render's image is incomplete */
+#define SALVE_STATUS_FP16_RANGE 2  /* resnet_forward: an activation exceeded the fp16 range and was saturated (no released
+                                      checkpoint does this; a network without normalisation can) */
 
 /* Library / ABI version (SALVE_HIP_ABI_VERSION). */
 int salve_hip_version(void);
@@ -96,22 +103,25 @@ size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n);
  *   dbg_mask    device uint8 [n, bev_h, bev_w] or NULL: hallucination mask (unflipped)
  *   dbg_stats   device int32 [n, 8] or NULL: {n_sites, min x, max x, occupied rows, walk iterations, error flag,
  *               sites handed to the general walk, queued triangles}
- *   out_in_window device int32 [n] or NULL: points inside the window per render (0 => the reference returns None, :279)
+ *   out_in_window device int32 [n] or NULL: points inside the window per render (0 => the reference returns None, :279,
+ *               and generate_texture_maps_for_pair writes no tile for the pair, :623-627)
+ *   status      device int32 status word or NULL (SALVE_STATUS_*)
  */
 int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth,
                            int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n,
                            uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
-                           int32_t* dbg_stats, int32_t* out_in_window, void* workspace, size_t workspace_bytes, void* stream);
+                           int32_t* dbg_stats, int32_t* out_in_window, int32_t* status, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* The two halves of salve_bev_render_batch as separate launches (same arguments, same workspace):
  * salve_bev_scatter fills the z-order key images (winning point index per pixel; the colours stay in pano_rgb, which
  * must remain valid until salve_bev_densify has run), salve_bev_densify turns them into BEV images.  Used by the
  * benchmark to time the dominant kernel on its own; render_batch == scatter followed by densify. */
 int salve_bev_scatter(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth, int32_t n_panos,
-                      const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, int16_t* dbg_img_xy, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, int16_t* dbg_img_xy, int32_t* out_in_window,
+                      void* workspace, size_t workspace_bytes, void* stream);
 int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, uint64_t* dbg_keys, uint8_t* dbg_mask,
-                      int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream);
+                      int32_t* dbg_stats, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Splat an explicit coloured point cloud -- the `xyzrgb` argument of render_bev_image (bev_rendering_utils.py:254-308):
  * xyz device double [n_points, 3] in the world frame, rgb device uint8 [n_points, 3] (the reference's float colours
@@ -210,13 +220,10 @@ void salve_resnet_destroy(void* handle);
 int salve_resnet_num_layers(void* handle);
 /* Device workspace needed for a batch (activation buffers). */
 size_t salve_resnet_workspace_bytes(void* handle, int32_t batch);
-/* input: device fp16 [batch, H, W, in_channels] (NHWC); logits: device float [batch, n_classes]. */
+/* input: device fp16 [batch, H, W, in_channels] (NHWC); logits: device float [batch, n_classes];
+ * status: device int32 status word or NULL (SALVE_STATUS_FP16_RANGE). */
 int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* logits, void* workspace,
-                         size_t workspace_bytes, void* stream);
-
-/* Development aid (not part of the hot path): a synthetic load kernel -- mode 0 MFMA only, 1 VALU only, 2 LDS reads only,
- * 3 MFMA + LDS -- used by tools/debug_overlap2.py to study co-residency with the rasteriser. */
-int salve_debug_burn(int32_t blocks, int32_t iters, int32_t mode, float* sink, void* stream);
+                         size_t workspace_bytes, int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,8 +37,9 @@ EXPORTED_SYMBOLS = (
     "salve_resnet_workspace_bytes",
     "salve_resnet_forward",
     "salve_resnet_num_layers",
-    "salve_debug_burn",
 )
+STATUS_WALK_FAILED = 1
+STATUS_FP16_RANGE = 2
 
 
 class BevConfig(ctypes.Structure):
@@ -87,11 +88,11 @@ def load() -> ctypes.CDLL:
     lib.salve_last_error.restype = ctypes.c_char_p
     lib.salve_bev_workspace_bytes.argtypes = [ctypes.POINTER(BevConfig), i32]
     lib.salve_bev_workspace_bytes.restype = sz
-    lib.salve_bev_render_batch.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.salve_bev_render_batch.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.salve_bev_render_batch.restype = ctypes.c_int
-    lib.salve_bev_scatter.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, sz, vp]
+    lib.salve_bev_scatter.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, sz, vp]
     lib.salve_bev_scatter.restype = ctypes.c_int
-    lib.salve_bev_densify.argtypes = [ctypes.POINTER(BevConfig), i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.salve_bev_densify.argtypes = [ctypes.POINTER(BevConfig), i32, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.salve_bev_densify.restype = ctypes.c_int
     lib.salve_bev_scatter_points.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, sz, vp]
     lib.salve_bev_scatter_points.restype = ctypes.c_int
@@ -113,14 +114,26 @@ def load() -> ctypes.CDLL:
     lib.salve_resnet_destroy.restype = None
     lib.salve_resnet_workspace_bytes.argtypes = [vp, i32]
     lib.salve_resnet_workspace_bytes.restype = sz
-    lib.salve_resnet_forward.argtypes = [vp, vp, i32, vp, vp, sz, vp]
+    lib.salve_resnet_forward.argtypes = [vp, vp, i32, vp, vp, sz, vp, vp]
     lib.salve_resnet_forward.restype = ctypes.c_int
     lib.salve_resnet_num_layers.argtypes = [vp]
     lib.salve_resnet_num_layers.restype = ctypes.c_int
+    # development entry point (salve_amd/csrc/salve_debug.h), not part of the product ABI
     lib.salve_debug_burn.argtypes = [i32, i32, i32, vp, vp]
     lib.salve_debug_burn.restype = ctypes.c_int
     _lib = lib
     return lib
+
+
+def check_status_word(word: int, what: str) -> None:
+    """Raise for a non-zero device status word (include/salve_hip.h: SALVE_STATUS_*)."""
+    if word & STATUS_WALK_FAILED:
+        raise SalveHipError(f"{what}: a Delaunay star walk did not close; the BEV image of at least one render is incomplete")
+    if word & STATUS_FP16_RANGE:
+        raise SalveHipError(f"{what}: an activation of the verifier exceeded the fp16 range and was saturated; the logits are "
+                            "not those of the fp32 network (a network without trained normalisation statistics does this)")
+    if word:
+        raise SalveHipError(f"{what}: device status word {word:#x}")
 
 
 def check(status: int, what: str) -> None:

@@ -76,7 +76,14 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
     // where the densify kernel finds the colour of point index i of this render: colour_src[rid] + 3 i
     if (blockIdx.x == 0 && threadIdx.x == 0) colour_src[rid] = rgb + ((size_t)h.pano_idx * c.pano_h + c.crop_rows) * c.pano_w * 3;
     const int p0 = (blockIdx.x * SCATTER_THREADS + threadIdx.x) * PTS_PER_THREAD;  // first point (cropped raster)
-    if (p0 >= c.npts) return;
+    __shared__ int block_in_window;
+    const bool counting = in_window != nullptr && pass == 0;   // (uniform)
+    if (counting) {
+        if (threadIdx.x == 0) block_in_window = 0;
+        __syncthreads();
+    }
+    int my_in_window = 0;
+    if (p0 < c.npts) {
     const int v = p0 / c.pano_w + c.crop_rows;
     const int u0 = p0 % c.pano_w;  // pano_w is a multiple of 4: the four points share the row
     const size_t pix = ((size_t)h.pano_idx * c.pano_h + v) * c.pano_w + u0;
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
                 const double fy = rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
                 ix = (int)fx;
                 iy = (int)fy;
-                if (in_window && pass == 0) atomicAdd(in_window + rid, 1);
+                my_in_window++;
                 const double zs = floor(z) - c.zmin;  // unit slices from an integer z_min: exact
                 if (zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H) {
                     const uint32_t key = ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | (uint32_t)(p0 + k);
@@ -138,6 +145,15 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
             o[0] = (int16_t)ix;
             o[1] = (int16_t)iy;
         }
+    }
+    }
+    if (counting) {
+        // points inside the window (prune_to_2d_bbox, :38-45): one LDS add per wave, one global atomic per workgroup --
+        // a device-scope atomic per point on ONE address per render would serialise at the memory side
+        for (int off = 32; off >= 1; off >>= 1) my_in_window += __shfl_xor(my_in_window, off);
+        if ((threadIdx.x & 63) == 0 && my_in_window) atomicAdd(&block_in_window, my_in_window);
+        __syncthreads();
+        if (threadIdx.x == 0 && block_in_window) atomicAdd(in_window + rid, block_in_window);
     }
 }
 
@@ -306,7 +322,7 @@ static int ensure_star_table() {
 __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     DevCfg c, const uint32_t* __restrict__ keys_all, const uint8_t* const* __restrict__ colour_src, uint32_t* __restrict__ bev_all,
     uint32_t* __restrict__ sitelist_all, uint32_t* __restrict__ hardlist_all, unsigned long long* __restrict__ triq_all,
-    uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats, int16_t* __restrict__ dbg_aux) {
+    uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats, int16_t* __restrict__ dbg_aux, int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = c.H, W = c.W, wpr = c.wpr;
     uint32_t* occ = reinterpret_cast<uint32_t*>(smem);
@@ -547,7 +563,11 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
 #if defined(SALVE_PROFILE_WALK)
         SD_LAP(e2_total, t_e2);
 #endif
-        if (err) atomicOr(&scal[5], 1);
+        if (err) {
+            atomicOr(&scal[5], 1);
+            // a star walk that did not close: the image of this render is incomplete -- tell the host (salve_hip.h: status word)
+            if (status && lane == 0) atomicOr(status, SALVE_STATUS_WALK_FAILED);
+        }
         for (int i = tid; i < ((c.dbg_flags & 8) ? 0 : nq); i += DENSIFY_THREADS) {
             const unsigned long long e = __hip_atomic_load(triq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int ax = (int)(e & 0xFFFFu), ay = (int)((e >> 16) & 0xFFFFu);
@@ -810,7 +830,7 @@ size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n) {
 static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* pano_rgb, const uint16_t* pano_depth,
                      int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, uint32_t* out_bev,
                      int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask, int32_t* dbg_stats, int32_t* in_window,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
     DevCfg d;
     if (!make_devcfg(cfg, &d)) return SALVE_ERR_BAD_ARG;
     if (n == 0) return SALVE_OK;
@@ -848,14 +868,22 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
     if (densify) {
         const int tab_status = ensure_star_table();
         if (tab_status != SALVE_OK) return tab_status;
-        static size_t attr_lds = 0;
-        if (lds > attr_lds) {  // opt in to more than 64 KB of dynamic LDS, for exactly what this launch uses
-            SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_lds = lds;
+        {   // opt in to more than 64 KB of dynamic LDS, for exactly what this launch uses: the attribute is kept per
+            // device (a second GPU in the process needs its own opt-in) under a mutex
+            static std::mutex mu;
+            static size_t attr_lds[64] = {0};
+            std::lock_guard<std::mutex> lock(mu);
+            int dev = 0;
+            SALVE_HIP_CHECK(hipGetDevice(&dev));
+            const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+            if (dev != slot || lds > attr_lds[slot]) {
+                SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_lds[slot] = lds;
+            }
         }
         hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, ws.keys, ws.colour_src, out_bev, ws.sitelist,
-                           ws.hardlist, ws.triq, dbg_mask, dbg_stats, (d.dbg_flags & 16) ? dbg_img_xy : nullptr);
+                           ws.hardlist, ws.triq, dbg_mask, dbg_stats, (d.dbg_flags & 16) ? dbg_img_xy : nullptr, status);
         SALVE_HIP_CHECK(hipGetLastError());
         if (dbg_keys) {
             const size_t total = (size_t)n * npx;
@@ -870,22 +898,23 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
 int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth,
                            int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n,
                            uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
-                           int32_t* dbg_stats, int32_t* out_in_window, void* workspace, size_t workspace_bytes, void* stream) {
+                           int32_t* dbg_stats, int32_t* out_in_window, int32_t* status, void* workspace, size_t workspace_bytes,
+                           void* stream) {
     return bev_stage(cfg, 3, pano_rgb, pano_depth, n_panos, sphere, hyps, n, out_bev, dbg_img_xy, dbg_keys, dbg_mask, dbg_stats,
-                     out_in_window, workspace, workspace_bytes, stream);
+                     out_in_window, status, workspace, workspace_bytes, stream);
 }
 
 int salve_bev_scatter(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth, int32_t n_panos,
-                      const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, int16_t* dbg_img_xy, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+                      const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, int16_t* dbg_img_xy, int32_t* out_in_window,
+                      void* workspace, size_t workspace_bytes, void* stream) {
     return bev_stage(cfg, 1, pano_rgb, pano_depth, n_panos, sphere, hyps, n, nullptr, dbg_img_xy, nullptr, nullptr, nullptr,
-                     nullptr, workspace, workspace_bytes, stream);
+                     out_in_window, nullptr, workspace, workspace_bytes, stream);
 }
 
 int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, uint64_t* dbg_keys, uint8_t* dbg_mask,
-                      int32_t* dbg_stats, void* workspace, size_t workspace_bytes, void* stream) {
+                      int32_t* dbg_stats, int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
     return bev_stage(cfg, 2, nullptr, nullptr, 0, nullptr, nullptr, n, out_bev, nullptr, dbg_keys, dbg_mask, dbg_stats,
-                     nullptr, workspace, workspace_bytes, stream);
+                     nullptr, status, workspace, workspace_bytes, stream);
 }
 
 int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, const uint8_t* rgb, int32_t n_points,

@@ -5,6 +5,7 @@
 
 #include "../../include/salve_hip.h"
 #include "salve_common.h"
+#include "salve_debug.h"
 
 namespace {
 typedef __attribute__((__ext_vector_type__(8))) __bf16 bf16x8;

@@ -41,6 +41,7 @@ struct ConvArgs {
     // second, point-wise source (SRC2 kernels): k-tiles from nkt1 on read Cin2 channels of in2 at (oy, ox) * stride2
     const uint16_t* in2;
     int Hi2, Wi2, Cin2, stride2, nkt1;
+    int32_t* status;        // device status word (salve_hip.h) or nullptr
 };
 
 // Activations and weights are IEEE half precision (fp16: 11 significand bits; the MFMA rate is that of bf16).  With bf16
@@ -50,6 +51,15 @@ __device__ __forceinline__ float act_to_f32(uint16_t v) { return (float)__builti
 __device__ __forceinline__ uint16_t f32_to_act(float f) {
     f = fminf(fmaxf(f, -65504.f), 65504.f);  // (a NaN stays a NaN through the conversion below)
     return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+// Saturation must not pass silently: every epilogue folds the magnitudes it stores into `amax` (v_max3_f32 with |.|
+// source modifiers: half an instruction per value) and reports once per thread when the fp16 range was exceeded.
+__device__ __forceinline__ void track4(float& amax, float v0, float v1, float v2, float v3) {
+    amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
+    amax = fmaxf(amax, fmaxf(fabsf(v2), fabsf(v3)));
+}
+__device__ __forceinline__ void report_range(int32_t* status, float amax) {
+    if (status && !(amax <= 65504.f)) atomicOr(status, SALVE_STATUS_FP16_RANGE);  // (!(<=): a NaN reports too)
 }
 
 typedef __attribute__((address_space(1))) const void* global_cptr;
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
         }
         __syncthreads();
     }
+    float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         const int ncol = wc * WN + j * 16 + 4 * (lane >> 4);  // this lane's 4 consecutive channels of tile column j
@@ -221,12 +232,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
             if (p.relu) {
                 v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
             }
+            track4(amax, v0, v1, v2, v3);
             uint2 o;
             o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
             o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
             *cell = o;
         }
     }
+    report_range(p.status, amax);
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < C_ITERS; it++) {
@@ -339,6 +352,7 @@ struct BottleneckArgs {
     const float *ba, *bb, *bc;
     const uint16_t* zeros;
     int B, H, W, tiles_x, tiles_y;
+    int32_t* status;
 };
 
 constexpr int BN_THREADS = 512;  // 8 waves: two workgroups per CU give 4 waves per SIMD to hide the many short phases
@@ -387,6 +401,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     const int frag_row = lane & 15, frag_q = lane >> 4;
     const int row_base = tid >> 3;
     const int chunk = (tid & 7) ^ ((row_base >> 1) & 7);   // source-side swizzle, as in conv_igemm_kernel
+    float amax = 0.f;
 
     // Wb stage `st` -> buffer st & 1 (6 or 8 loads per thread)
 #define ISSUE_WB(ST)                                                                                                   \
@@ -477,6 +492,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const float4 bias = *reinterpret_cast<const float4*>(p.ba + c0);
                 float v0 = fmaxf(acc[i][j][0] + bias.x, 0.f), v1 = fmaxf(acc[i][j][1] + bias.y, 0.f);
                 float v2 = fmaxf(acc[i][j][2] + bias.z, 0.f), v3 = fmaxf(acc[i][j][3] + bias.w, 0.f);
+                track4(amax, v0, v1, v2, v3);
                 uint2 o;
                 o.x = inside ? ((uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16)) : 0u;
                 o.y = inside ? ((uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16)) : 0u;
@@ -539,9 +555,12 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             for (int j = 0; j < NT2; j++) {
                 const int c0 = (wc * NT2 + j) * 16 + 4 * frag_q;
                 const float4 bias = *reinterpret_cast<const float4*>(p.bb + c0);
+                const float v0 = fmaxf(acc[i][j][0] + bias.x, 0.f), v1 = fmaxf(acc[i][j][1] + bias.y, 0.f);
+                const float v2 = fmaxf(acc[i][j][2] + bias.z, 0.f), v3 = fmaxf(acc[i][j][3] + bias.w, 0.f);
+                track4(amax, v0, v1, v2, v3);
                 uint2 o;
-                o.x = (uint32_t)f32_to_act(fmaxf(acc[i][j][0] + bias.x, 0.f)) | ((uint32_t)f32_to_act(fmaxf(acc[i][j][1] + bias.y, 0.f)) << 16);
-                o.y = (uint32_t)f32_to_act(fmaxf(acc[i][j][2] + bias.z, 0.f)) | ((uint32_t)f32_to_act(fmaxf(acc[i][j][3] + bias.w, 0.f)) << 16);
+                o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
+                o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
                 *reinterpret_cast<uint2*>(T2 + m * MID + (((c0 >> 3) ^ swz) << 3) + (c0 & 7)) = o;
             }
         }
@@ -611,6 +630,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                     const float v1 = fmaxf(acc[i][j][1] + bias.y + act_to_f32((uint16_t)(r.x >> 16)), 0.f);
                     const float v2 = fmaxf(acc[i][j][2] + bias.z + act_to_f32((uint16_t)(r.y & 0xFFFFu)), 0.f);
                     const float v3 = fmaxf(acc[i][j][3] + bias.w + act_to_f32((uint16_t)(r.y >> 16)), 0.f);
+                    track4(amax, v0, v1, v2, v3);
                     uint2 o;
                     o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
                     o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
@@ -631,6 +651,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             __syncthreads();  // staging and Wc tile are reused by the next chunk
         }
     }
+    report_range(p.status, amax);
 }
 
 struct ResnetHandle {
@@ -758,7 +779,7 @@ size_t salve_resnet_workspace_bytes(void* handle, int32_t batch) {
 }
 
 int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* logits, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+                         size_t workspace_bytes, int32_t* status, void* stream) {
     ResnetHandle* h = reinterpret_cast<ResnetHandle*>(handle);
     if (!h || !input || !logits || !workspace || batch <= 0) {
         salve_fail("salve_resnet_forward: null argument or bad batch");
@@ -782,7 +803,7 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.wa = h->d_weights + o.w_off; a.wb = h->d_weights + ob.w_off; a.wc = h->d_weights + oc.w_off;
             a.ba = h->d_params + o.b_off; a.bb = h->d_params + ob.b_off; a.bc = h->d_params + oc.b_off;
             a.zeros = h->d_zeros;
-            a.B = batch; a.H = o.Hi; a.W = o.Wi;
+            a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status;
             a.tiles_x = (o.Wi + 15) / 16;
             const bool narrow = o.Cout == 64;  // 64 mid channels: 8 x 16 pixel tiles; 128: 4 x 16
             a.tiles_y = o.Hi / (narrow ? 8 : 4);
@@ -803,6 +824,7 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.out = buf(o.out_buf);
             a.ktab = h->d_ktab + o.ktab_off;
             a.zeros = h->d_zeros;
+            a.status = status;
             a.B = batch; a.Hi = o.Hi; a.Wi = o.Wi; a.Cin = o.Cin; a.Ho = o.Ho; a.Wo = o.Wo; a.Cout = o.Cout;
             a.stride = o.stride; a.pad = o.pad; a.K = o.KH * o.KW * o.Cin; a.relu = o.relu;
             const bool src2 = o.in2_buf != SALVE_NO_BUF;

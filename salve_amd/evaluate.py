@@ -121,24 +121,41 @@ def evaluate_model(serialization_save_dir: str, ckpt_fpath: str, args, split: st
 def run_fused_epoch(pipe, hypotheses, tile_names: Sequence[Sequence[str]], y_true: Optional[np.ndarray], serialization_save_dir: str,
                     batch_size: int = 64, ckpt_fpath: str = "", split: str = "test", world: int = 1, rank: int = 0) -> Dict[str, Any]:
     """Render + verify a hypothesis table on the GPU (pipeline.RenderVerifyPipeline) and write the SAME prediction
-    files as run_test_epoch.  `tile_names[j]` = (fp0, fp1): the floor-tile paths the un-fused path would have written
-    for hypothesis j (utils/bev_rendering_utils.bev_fname_from_img_fpath under `{root}/{label}/{building}/`); they are
+    files as run_test_epoch.  `hypotheses`, `tile_names` and `y_true` describe the WHOLE table on every rank;
+    `tile_names[j]` = (fp0, fp1): the tile paths the un-fused path would have written for hypothesis j
+    (utils/bev_rendering_utils.bev_fname_from_img_fpath under `{root}/{label}/{building}/`, in file-name order); they are
     only used as names.  y_true: [N] labels (0 / 1) or None (then 0).  With world > 1 every rank scores its contiguous
-    shard (the table passed in must already be the shard) and rank 0 writes the files after the all-gather of logits."""
+    block (HypothesisTable.shard) and rank 0 writes the files after the path's one all-gather.
+
+    Hypotheses with a render that has no point inside the BEV window are dropped: the reference writes no tile for them
+    (bev_rendering_utils.py:279-280, 623-627), so they never reach scripts/test.py nor the pose-graph stage."""
     from salve_amd.pipeline import gather_logits
 
-    prepared = pipe.prepare(hypotheses)
-    logits = gather_logits(pipe.score(prepared), world)
-    probs = torch.softmax(logits, dim=1)  # train_utils.py:31
+    n_all = len(hypotheses)
+    shard = hypotheses.shard(rank, world) if world > 1 else hypotheses
+    prepared = pipe.prepare(shard)
+    local = pipe.score(prepared)
+    valid_local = torch.from_numpy(pipe.valid_mask(prepared).astype(np.float32)).to(local.device)
+    pipe.check("run_fused_epoch")
+    # one collective: the validity flag rides along as an extra column of the logits
+    both = gather_logits(torch.cat([local, valid_local[:, None]], dim=1), world, total=n_all)
+    logits, valid = both[:, :-1], both[:, -1] > 0.5
+    keep = torch.nonzero(valid).reshape(-1)
+    probs = torch.softmax(logits[keep], dim=1)  # train_utils.py:31
     y_hat = torch.argmax(probs, dim=1)
     n = int(probs.shape[0])
-    gt = torch.zeros(n, dtype=torch.long, device=probs.device) if y_true is None else torch.as_tensor(np.asarray(y_true), device=probs.device).long()
-    cls, pr = ClassAccuracyMeter(int(probs.shape[1])), PrecisionRecallMeter()
+    gt_all = torch.zeros(n_all, dtype=torch.long, device=probs.device) if y_true is None else torch.as_tensor(np.asarray(y_true), device=probs.device).long()
+    gt = gt_all[keep]
+    cls, pr = ClassAccuracyMeter(int(logits.shape[1])), PrecisionRecallMeter()
     cls.update(y_hat.cpu().numpy(), gt.cpu().numpy())
     pr.update(y_true=gt.cpu().numpy(), y_hat=y_hat.cpu().numpy())
     if rank == 0:
+        kept = keep.cpu().numpy().tolist()
         for b, lo in enumerate(range(0, n, batch_size)):
             hi = min(lo + batch_size, n)
             save_edge_classifications_to_disk(serialization_save_dir, b, y_hat[lo:hi], gt[lo:hi], probs[lo:hi],
-                                              [tile_names[j][0] for j in range(lo, hi)], [tile_names[j][1] for j in range(lo, hi)])
-    return _summary(split, ckpt_fpath, cls, pr)
+                                              [tile_names[kept[j]][0] for j in range(lo, hi)], [tile_names[kept[j]][1] for j in range(lo, hi)])
+    out = _summary(split, ckpt_fpath, cls, pr)
+    out["num_hypotheses"] = n_all
+    out["num_dropped_no_points_in_window"] = n_all - n
+    return out

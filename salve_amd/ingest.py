@@ -17,7 +17,7 @@ import ctypes
 import glob
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -118,19 +118,31 @@ class FloorHypotheses:
     def __len__(self) -> int:
         return len(self.fpaths)
 
-    def table(self, store: PanoStore) -> HypothesisTable:
-        """Rows for pipeline.RenderVerifyPipeline.prepare: pano ids -> store indices."""
+    def swap(self, img_fpaths: Dict[int, str]) -> np.ndarray:
+        """bool [N]: True where the tile of pano i2 sorts BEFORE the tile of pano i1.  The reference's dataset orders the
+        two tiles of a pair by file name (salve/dataset/zind_data.py:110 `pair_fpaths.sort()`); the names differ only in
+        the pano stem (bev_rendering_utils.py:582-595), e.g. `..partial_room_07_pano_5` > `..partial_room_04_pano_8` and
+        `pano_10` < `pano_9` -- not the order of (i1, i2).  The verifier's first image is the one whose name sorts first."""
+        return np.array([Path(img_fpaths[int(a)]).stem > Path(img_fpaths[int(b)]).stem for a, b in zip(self.i1, self.i2)], dtype=bool)
+
+    def table(self, store: PanoStore, img_fpaths: Optional[Dict[int, str]] = None) -> HypothesisTable:
+        """Rows for pipeline.RenderVerifyPipeline.prepare: pano ids -> store indices, tile order from the file names."""
         ix = lambda ids: np.array([store.index[int(p)] for p in ids], dtype=np.int32)
+        if img_fpaths is None:
+            img_fpaths = {pid: store.fpaths[k] for pid, k in store.index.items()}
         return HypothesisTable(i1=ix(self.i1), i2=ix(self.i2), R=self.R.astype(np.float32), t=self.t.astype(np.float32),
-                               theta_deg=np.degrees(np.arctan2(self.R[:, 1, 0], self.R[:, 0, 0])).astype(np.float64))
+                               theta_deg=np.degrees(np.arctan2(self.R[:, 1, 0], self.R[:, 0, 0])).astype(np.float64),
+                               swap=self.swap(img_fpaths))
 
     def tile_names(self, bev_save_root: str, img_fpaths: Dict[int, str], surface_type: str = "floor") -> List[Tuple[str, str]]:
-        """The two tile paths generate_texture_maps_for_pair would write per hypothesis (bev_rendering_utils.py:579-595)."""
+        """(fp0, fp1) per hypothesis: the two tile paths generate_texture_maps_for_pair would write
+        (bev_rendering_utils.py:579-595), in the sorted order in which the reference's dataset hands them to the verifier and
+        scripts/test.py writes them to the prediction files (zind_data.py:110, 306-315)."""
         out = []
         for j in range(len(self)):
             d = f"{bev_save_root}/{LABEL_TYPES[0] if self.label[j] else LABEL_TYPES[1]}/{self.building_id}"
-            out.append(tuple(f"{d}/{bev_fname_from_img_fpath(int(self.pair_idx[j]), self.pair_uuid[j], surface_type, img_fpaths[int(p)])}"
-                             for p in (self.i1[j], self.i2[j])))
+            out.append(tuple(sorted(f"{d}/{bev_fname_from_img_fpath(int(self.pair_idx[j]), self.pair_uuid[j], surface_type, img_fpaths[int(p)])}"
+                                    for p in (self.i1[j], self.i2[j]))))
         return out
 
 
@@ -168,5 +180,5 @@ def score_floor(model, device, raw_dataset_dir: str, depth_save_root: str, hypot
     store = PanoStore(device).load(img_fpaths, depth_save_root, building_id, np.concatenate([hyps.i1, hyps.i2]))
     pipe = RenderVerifyPipeline(model, device, pano_hw=store.pano_hw, chunk=chunk)
     pipe.set_panos(store.rgb, store.depth)
-    return evaluate.run_fused_epoch(pipe, hyps.table(store), hyps.tile_names(bev_save_root, img_fpaths), hyps.label, serialization_save_dir,
-                                    batch_size=batch_size)
+    return evaluate.run_fused_epoch(pipe, hyps.table(store, img_fpaths), hyps.tile_names(bev_save_root, img_fpaths), hyps.label,
+                                    serialization_save_dir, batch_size=batch_size)

@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 import numpy as np
 import torch
 
-from salve_amd import _lib
+from salve_amd import _lib, status
 from salve_amd.models.resnet_factory import RESNET_SPECS
 
 OP_CONV, OP_MAXPOOL, OP_AVGPOOL_FC = 0, 1, 2
@@ -204,10 +204,12 @@ class HipResNet:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         if out is None:
             out = torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)
-        st = self.lib.salve_resnet_forward(
-            self.handle, ctypes.c_void_p(x.data_ptr()), B, ctypes.c_void_p(out.data_ptr()),
-            ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
-        )
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_resnet_forward(
+                self.handle, ctypes.c_void_p(x.data_ptr()), B, ctypes.c_void_p(out.data_ptr()),
+                ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel(), status.ptr(self.device),
+                ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
+            )
         _lib.check(st, "salve_resnet_forward")
         return out
 

@@ -13,7 +13,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from salve_amd import _lib
+from salve_amd import _lib, status
 from salve_amd.common.bevparams import BEVParams
 from salve_amd.utils import rotation_utils
 from salve_amd.utils.hohonet_pano_utils import get_sphere_factors
@@ -157,27 +157,34 @@ class BevRasteriser:
         ws = self._workspace(n)
         P = int(pano_rgb.shape[0])
         ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
-        st = self.lib.salve_bev_render_batch(
-            ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), P, ptr(self.sphere), ptr(hyps_dev), n,
-            ptr(out_bev), ptr(dbg.img_xy), ptr(dbg.keys), ptr(dbg.mask), ptr(dbg.stats), ptr(dbg.in_window), ptr(ws), ws.numel(), self._stream(),
-        )
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_render_batch(
+                ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), P, ptr(self.sphere), ptr(hyps_dev), n,
+                ptr(out_bev), ptr(dbg.img_xy), ptr(dbg.keys), ptr(dbg.mask), ptr(dbg.stats), ptr(dbg.in_window), status.ptr(self.device),
+                ptr(ws), ws.numel(), self._stream(),
+            )
         _lib.check(st, "salve_bev_render_batch")
         return out_bev, dbg
 
-    def scatter(self, pano_rgb: torch.Tensor, pano_depth: torch.Tensor, hyps_dev: torch.Tensor, n: int) -> None:
-        """First half of `render`: z-order key images into the workspace."""
+    def scatter(self, pano_rgb: torch.Tensor, pano_depth: torch.Tensor, hyps_dev: torch.Tensor, n: int,
+                in_window: Optional[torch.Tensor] = None) -> None:
+        """First half of `render`: z-order key images into the workspace.  `in_window` (int32 [n]) receives the number of
+        points inside the window per render (0 => the reference writes no tile, bev_rendering_utils.py:279, 623-627)."""
         ws = self._workspace(n)
-        st = self.lib.salve_bev_scatter(
-            ctypes.byref(self.cfg), ctypes.c_void_p(pano_rgb.data_ptr()), ctypes.c_void_p(pano_depth.data_ptr()),
-            int(pano_rgb.shape[0]), ctypes.c_void_p(self.sphere.data_ptr()), ctypes.c_void_p(hyps_dev.data_ptr()), n, None,
-            ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_scatter(
+                ctypes.byref(self.cfg), ctypes.c_void_p(pano_rgb.data_ptr()), ctypes.c_void_p(pano_depth.data_ptr()),
+                int(pano_rgb.shape[0]), ctypes.c_void_p(self.sphere.data_ptr()), ctypes.c_void_p(hyps_dev.data_ptr()), n, None,
+                ctypes.c_void_p(0 if in_window is None else in_window.data_ptr()),
+                ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
         _lib.check(st, "salve_bev_scatter")
 
     def densify(self, n: int, out_bev: torch.Tensor) -> torch.Tensor:
         """Second half of `render`: key images -> BEV images."""
         ws = self._workspace(n)
-        st = self.lib.salve_bev_densify(ctypes.byref(self.cfg), n, ctypes.c_void_p(out_bev.data_ptr()), None, None, None,
-                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_densify(ctypes.byref(self.cfg), n, ctypes.c_void_p(out_bev.data_ptr()), None, None, None,
+                                            status.ptr(self.device), ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
         _lib.check(st, "salve_bev_densify")
         return out_bev
 
@@ -186,9 +193,10 @@ class BevRasteriser:
         """`render` that also reports, per render, how many points fell inside the window (int32 [n])."""
         ws = self._workspace(n)
         ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
-        st = self.lib.salve_bev_render_batch(
-            ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), int(pano_rgb.shape[0]), ptr(self.sphere), ptr(hyps_dev), n,
-            ptr(out_bev), None, None, None, None, ptr(counts), ptr(ws), ws.numel(), self._stream())
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_render_batch(
+                ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), int(pano_rgb.shape[0]), ptr(self.sphere), ptr(hyps_dev), n,
+                ptr(out_bev), None, None, None, None, ptr(counts), status.ptr(self.device), ptr(ws), ws.numel(), self._stream())
         _lib.check(st, "salve_bev_render_batch")
 
     def render_points(self, xyz: np.ndarray, rgb_u8: np.ndarray):
@@ -197,9 +205,10 @@ class BevRasteriser:
         rgb_d = torch.from_numpy(np.ascontiguousarray(rgb_u8, dtype=np.uint8)).to(self.device)
         cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
         ws = self._workspace(1)
-        st = self.lib.salve_bev_scatter_points(ctypes.byref(self.cfg), ctypes.c_void_p(xyz_d.data_ptr()), ctypes.c_void_p(rgb_d.data_ptr()),
-                                               int(xyz_d.shape[0]), ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                                               ws.numel(), self._stream())
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_scatter_points(ctypes.byref(self.cfg), ctypes.c_void_p(xyz_d.data_ptr()), ctypes.c_void_p(rgb_d.data_ptr()),
+                                                   int(xyz_d.shape[0]), ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                                   ws.numel(), self._stream())
         _lib.check(st, "salve_bev_scatter_points")
         Hb, Wb = self.bev_hw
         bev = self.densify(1, torch.empty((1, Hb, Wb), dtype=torch.int32, device=self.device))
@@ -209,7 +218,8 @@ class BevRasteriser:
         """int32 [n,H,W] -> uint8 [n,H,W,3] (the array `render_bev_image` returns)."""
         n, Hb, Wb = bev.shape
         out = torch.empty((n, Hb, Wb, 3), dtype=torch.uint8, device=self.device)
-        st = self.lib.salve_bev_export_u8(ctypes.c_void_p(bev.data_ptr()), n, Hb, Wb, ctypes.c_void_p(out.data_ptr()), self._stream())
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_export_u8(ctypes.c_void_p(bev.data_ptr()), n, Hb, Wb, ctypes.c_void_p(out.data_ptr()), self._stream())
         _lib.check(st, "salve_bev_export_u8")
         return out
 
@@ -224,10 +234,11 @@ class BevRasteriser:
     def tiles(self, bev: torch.Tensor, jobs_dev: torch.Tensor, n_jobs: int, out: torch.Tensor, fmt: int, out_c: int) -> torch.Tensor:
         """Resize -> crop -> normalise into `out` (float32 NCHW or fp16 NHWC, see include/salve_hip.h)."""
         Hb, Wb = self.bev_hw
-        st = self.lib.salve_bev_tiles(
-            ctypes.c_void_p(bev.data_ptr()), Hb, Wb, ctypes.c_void_p(jobs_dev.data_ptr()), n_jobs,
-            ctypes.c_void_p(self.coef_y.data_ptr()), ctypes.c_void_p(self.coef_x.data_ptr()), self.resize, self.crop,
-            ctypes.c_void_p(self.lut.data_ptr()), ctypes.c_void_p(out.data_ptr()), fmt, out_c, self._stream(),
-        )
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_tiles(
+                ctypes.c_void_p(bev.data_ptr()), Hb, Wb, ctypes.c_void_p(jobs_dev.data_ptr()), n_jobs,
+                ctypes.c_void_p(self.coef_y.data_ptr()), ctypes.c_void_p(self.coef_x.data_ptr()), self.resize, self.crop,
+                ctypes.c_void_p(self.lut.data_ptr()), ctypes.c_void_p(out.data_ptr()), fmt, out_c, self._stream(),
+            )
         _lib.check(st, "salve_bev_tiles")
         return out

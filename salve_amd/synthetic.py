@@ -21,7 +21,7 @@ given (pano index, H, W) / (seed, N, P).
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -69,9 +69,65 @@ def make_pano_rgb(pano_idx: int, H: int = 512, W: int = 1024) -> np.ndarray:
     return img
 
 
-def make_pano(pano_idx: int, H: int = 512, W: int = 1024) -> Tuple[np.ndarray, np.ndarray]:
-    """(rgb uint8 [H,W,3], depth uint16 [H,W])."""
-    return make_pano_rgb(pano_idx, H, W), make_box_room_depth_mm(pano_idx, H, W)
+def make_cluttered_room_depth_mm(pano_idx: int, H: int = 512, W: int = 1024) -> np.ndarray:
+    """uint16 [H, W] depth in millimetres of the jittered box room of `make_box_room_depth_mm` with 3-5 occluding boxes
+    standing on the floor (furniture: 0.4-1.1 m wide, 0.4-1.9 m tall, never over the camera) and a door opening in the +x
+    wall (0.9 m wide, 2.0 m tall) through which the rays continue into a 2 m deep corridor.  The floor and ceiling clouds of
+    this scene have shadows behind the furniture and a notch at the door: a NON-convex outline with interior holes, which is
+    what raises the share of sites the lean star walk hands to the general walk."""
+    rng = np.random.default_rng(seed=pano_idx)
+    jit = rng.uniform(-WALL_JITTER, WALL_JITTER, size=4)          # same walls as the box room of this pano index
+    x0, x1 = WALL_X[0] + jit[0], WALL_X[1] + jit[1]
+    y0, y1 = WALL_Y[0] + jit[2], WALL_Y[1] + jit[3]
+    rng = np.random.default_rng(seed=7_000_003 + pano_idx)
+    d = get_uni_sphere_xyz(H, W)
+    dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = [np.where(c != 0, 1.0 / c, np.inf) for c in (dx, dy, dz)]
+        # room shell; the +x wall has a door opening y in [ya, ya + 0.9], z below FLOOR_Z + 2.0, behind it a corridor
+        ya = rng.uniform(y0 + 0.3, y1 - 1.2)
+        corridor = 2.0
+        tz = np.where(dz > 0, CEILING_Z * inv[2], np.where(dz < 0, FLOOR_Z * inv[2], np.inf))
+        ty = np.where(dy > 0, y1 * inv[1], np.where(dy < 0, y0 * inv[1], np.inf))
+        tx_near = np.where(dx > 0, x1 * inv[0], np.where(dx < 0, x0 * inv[0], np.inf))
+        hit_y, hit_z = tx_near * dy, tx_near * dz
+        through = (dx > 0) & (hit_y >= ya) & (hit_y <= ya + 0.9) & (hit_z <= FLOOR_Z + 2.0)
+        # inside the corridor the side walls are the door jambs, the far wall is at x1 + corridor
+        ty_corr = np.where(dy > 0, (ya + 0.9) * inv[1], np.where(dy < 0, ya * inv[1], np.inf))
+        tz_corr = np.where(dz > 0, (FLOOR_Z + 2.0) * inv[2], np.where(dz < 0, FLOOR_Z * inv[2], np.inf))
+        t_corr = np.minimum(np.minimum((x1 + corridor) * inv[0], ty_corr), tz_corr)
+        t = np.minimum(np.minimum(np.where(through, np.inf, tx_near), ty), tz)
+        t = np.where(through & (tx_near <= np.minimum(ty, tz)), t_corr, t)
+        # furniture: axis-aligned boxes on the floor, slab test (the camera is outside every box)
+        for _ in range(int(rng.integers(3, 6))):
+            w, dpt, h = rng.uniform(0.4, 1.1), rng.uniform(0.4, 1.1), rng.uniform(0.4, 1.9)
+            for _try in range(20):
+                bx, by = rng.uniform(x0 + 0.1, x1 - w - 0.1), rng.uniform(y0 + 0.1, y1 - dpt - 0.1)
+                if not (bx - 0.35 < 0 < bx + w + 0.35 and by - 0.35 < 0 < by + dpt + 0.35):
+                    break
+            else:
+                continue
+            lo = np.array([bx, by, FLOOR_Z])
+            hi = np.array([bx + w, by + dpt, min(FLOOR_Z + h, CEILING_Z - 0.05)])
+            t_in, t_out = np.full(dx.shape, -np.inf), np.full(dx.shape, np.inf)
+            for a in range(3):
+                ta, tb = lo[a] * inv[a], hi[a] * inv[a]
+                par = ~np.isfinite(inv[a])                      # ray parallel to this slab: origin 0 must lie inside it
+                inside = (lo[a] <= 0.0) & (0.0 <= hi[a])
+                t_in = np.where(par, np.where(inside, t_in, np.inf), np.maximum(t_in, np.minimum(ta, tb)))
+                t_out = np.where(par, t_out, np.minimum(t_out, np.maximum(ta, tb)))
+            hit = (t_in < t_out) & (t_in > 0)
+            t = np.where(hit, np.minimum(t, t_in), t)
+    mm = np.round(t * 1000.0)
+    return np.clip(mm, 0, 65535).astype(np.uint16)
+
+
+SCENES = {"box": make_box_room_depth_mm, "cluttered": make_cluttered_room_depth_mm}
+
+
+def make_pano(pano_idx: int, H: int = 512, W: int = 1024, scene: str = "box") -> Tuple[np.ndarray, np.ndarray]:
+    """(rgb uint8 [H,W,3], depth uint16 [H,W]).  scene: "box" (the benchmark's scene) or "cluttered"."""
+    return make_pano_rgb(pano_idx, H, W), SCENES[scene](pano_idx, H, W)
 
 
 @dataclass
@@ -83,16 +139,23 @@ class HypothesisTable:
     R: np.ndarray  # float32 [N, 2, 2]
     t: np.ndarray  # float32 [N, 2]
     theta_deg: np.ndarray  # float64 [N]
+    # bool [N] or None: True where the verifier must see (pano i2, pano i1) instead of (i1, i2).  The reference's dataset
+    # orders the two tiles of a pair by FILE NAME (salve/dataset/zind_data.py:110 `pair_fpaths.sort()`), i.e. by pano stem,
+    # not by (i1, i2); released checkpoints were trained that way.  Synthetic tables have no names: no swap.
+    swap: Optional[np.ndarray] = None
 
     def __len__(self) -> int:
         return int(self.i1.shape[0])
 
+    @staticmethod
+    def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+        """Contiguous block split, rank r gets rows [r*N/G, (r+1)*N/G); sizes differ by at most one."""
+        return (rank * n) // world, ((rank + 1) * n) // world
+
     def shard(self, rank: int, world: int) -> "HypothesisTable":
-        """Contiguous block split, rank r gets rows [r*N/G, (r+1)*N/G)."""
-        n = len(self)
-        lo = (rank * n) // world
-        hi = ((rank + 1) * n) // world
-        return HypothesisTable(self.i1[lo:hi], self.i2[lo:hi], self.R[lo:hi], self.t[lo:hi], self.theta_deg[lo:hi])
+        lo, hi = self.shard_bounds(len(self), rank, world)
+        return HypothesisTable(self.i1[lo:hi], self.i2[lo:hi], self.R[lo:hi], self.t[lo:hi], self.theta_deg[lo:hi],
+                               None if self.swap is None else self.swap[lo:hi])
 
 
 def make_hypotheses(n: int, num_panos: int, seed: int = 0) -> HypothesisTable:

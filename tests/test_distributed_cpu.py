@@ -27,13 +27,15 @@ def _worker(rank, world, port, n, out_dir):
     shard = table.shard(rank, world)
     # stand-in for the verifier: a deterministic function of the hypothesis, so the gathered order can be checked
     local = torch.from_numpy(np.stack([shard.theta_deg, shard.t[:, 0].astype(np.float64)], 1)).float()
-    full = gather_logits(local, world)
+    full = gather_logits(local, world, total=n)
     torch.save(full, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_shard_and_all_gather(tmp_path):
-    n, world = 64, 2
+@pytest.mark.parametrize("n,world", [(64, 2), (65, 2), (64, 3)])
+def test_shard_and_all_gather(tmp_path, n, world):
+    """Equal and unequal shards (65 rows over 2 ranks, 64 over 3): the single all_gather_into_tensor runs on blocks padded to
+    ceil(n / world) rows and the padding is dropped, so every rank ends with the table in its original order."""
     mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
     table = synthetic.make_hypotheses(n, 5, seed=0)
     expect = torch.from_numpy(np.stack([table.theta_deg, table.t[:, 0].astype(np.float64)], 1)).float()
@@ -41,8 +43,91 @@ def test_shard_and_all_gather(tmp_path):
         assert torch.equal(torch.load(tmp_path / f"r{r}.pt"), expect)
 
 
+class _StubPipeline:
+    """Stands in for pipeline.RenderVerifyPipeline in the N > 1 driver test below (the real one needs the GPU): logits are
+    a deterministic function of the hypothesis, hypotheses with t_x > 1.5 count as "no point inside the window"."""
+
+    def prepare(self, shard):
+        return shard
+
+    def score(self, shard):
+        return torch.from_numpy(np.stack([shard.t[:, 0], shard.t[:, 1]], 1).astype(np.float32))
+
+    def valid_mask(self, shard):
+        return shard.t[:, 0] <= 1.5
+
+    def check(self, what):
+        pass
+
+
+def _epoch_worker(rank, world, port, n, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from salve_amd import evaluate
+
+    table = synthetic.make_hypotheses(n, 5, seed=1)
+    names = [(f"/bev/gt_alignment_approx/0001/a_{j}.jpg", f"/bev/gt_alignment_approx/0001/b_{j}.jpg") for j in range(n)]
+    m = evaluate.run_fused_epoch(_StubPipeline(), table, names, np.arange(n) % 2, os.path.join(out_dir, "preds"), batch_size=16, world=world, rank=rank)
+    torch.save(m, os.path.join(out_dir, f"m{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(37, 2), (50, 3)])
+def test_fused_epoch_driver_on_several_ranks(tmp_path, n, world):
+    """evaluate.run_fused_epoch with world > 1 (gloo): every rank is handed the WHOLE table, scores its own block, the one
+    all-gather carries logits and the validity flag, rank 0 writes the prediction files -- without the hypotheses whose
+    renders had no point inside the window, in table order."""
+    import json
+
+    mp.spawn(_epoch_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    table = synthetic.make_hypotheses(n, 5, seed=1)
+    keep = np.nonzero(table.t[:, 0] <= 1.5)[0]
+    assert 0 < len(keep) < n
+    files = sorted((tmp_path / "preds").glob("batch_*.json"), key=lambda f: int(f.stem.split("_")[1]))
+    got = [json.load(open(f)) for f in files]
+    assert len(files) == -(-len(keep) // 16)
+    assert sum((g["fp0"] for g in got), []) == [f"/bev/gt_alignment_approx/0001/a_{j}.jpg" for j in keep]
+    assert sum((g["y_true"] for g in got), []) == (keep % 2).tolist()
+    assert sum((g["y_hat"] for g in got), []) == np.argmax(table.t[keep], 1).tolist()
+    metrics = [torch.load(tmp_path / f"m{r}.pt", weights_only=False) for r in range(world)]
+    assert all(m["num_hypotheses"] == n and m["num_dropped_no_points_in_window"] == n - len(keep) for m in metrics)
+    assert all(m["mean_accuracy"] == metrics[0]["mean_accuracy"] for m in metrics)
+
+
+def test_bench_starts_its_own_launcher_for_several_gpus(monkeypatch):
+    """`python bench.py --gpus 8` without a launcher must start torch.distributed.run as a CHILD process (never exec, and
+    before any GPU call) and relay its exit code."""
+    import importlib
+    import subprocess
+    import sys
+
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert cmd[-7].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not torch.cuda.is_initialized()
+
+
 def test_shards_partition_the_table():
     table = synthetic.make_hypotheses(4096, 64, seed=0)
     for world in (1, 2, 4, 8):
         sizes = [len(table.shard(r, world)) for r in range(world)]
         assert sizes == [4096 // world] * world
+    odd = synthetic.make_hypotheses(4099, 64, seed=0)
+    for world in (2, 3, 8):
+        shards = [odd.shard(r, world) for r in range(world)]
+        assert sum(len(s) for s in shards) == 4099 and max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+        assert np.array_equal(np.concatenate([s.theta_deg for s in shards]), odd.theta_deg)

@@ -30,16 +30,18 @@ def test_pano_resize_kernel_matches_oracle(src_hw, dst_hw):
         assert np.array_equal(got[k], bo.resize_pano_u8(img[k], dst_hw))
 
 
-def make_floor(tmp_path, n_panos=4, n_hyp=6):
+def make_floor(tmp_path, n_panos=4, n_hyp=6, reverse_rooms=False, far=()):
     """A synthetic building on disk in the reference's layout: 2048x1024 JPEG panoramas, 1024x512 .depth.png maps,
-    Sim(2) hypothesis files."""
+    Sim(2) hypothesis files.  reverse_rooms: partial-room numbers run against the pano ids, so the file-name order of
+    a pair's tiles disagrees with (i1, i2) wherever i1 < i2.  far: hypotheses whose translation puts pano i1 outside the
+    BEV window altogether."""
     raw, depth_root, hyp_root = tmp_path / "zind", tmp_path / "depth", tmp_path / "hyp"
     (raw / "0003" / "panos").mkdir(parents=True)
     fpaths = {}
     for i in range(n_panos):
         rgb, depth = synthetic.make_pano(i)
         big = np.repeat(np.repeat(rgb, 2, axis=0), 2, axis=1)            # 2048 x 1024
-        fp = raw / "0003" / "panos" / f"floor_01_partial_room_{i:02d}_pano_{i + 3}.jpg"
+        fp = raw / "0003" / "panos" / f"floor_01_partial_room_{(n_panos - 1 - i) if reverse_rooms else i:02d}_pano_{i + 3}.jpg"
         image_io.write_jpeg(str(fp), big)
         image_io.write_depth_png(str(depth_root / "0003" / f"{fp.stem}.depth.png"), depth)
         fpaths[i + 3] = str(fp)
@@ -48,6 +50,8 @@ def make_floor(tmp_path, n_panos=4, n_hyp=6):
         label = "gt_alignment_approx" if j % 3 == 0 else "incorrect_alignment"
         d = hyp_root / "0003" / "floor_01" / label
         d.mkdir(parents=True, exist_ok=True)
+        if j in far:
+            hyp.t[j] = np.array([40.0, -35.0], dtype=np.float32)
         Sim2(hyp.R[j].astype(np.float64), hyp.t[j].astype(np.float64), 1.0).save_as_json(
             str(d / f"{int(hyp.i1[j]) + 3}_{int(hyp.i2[j]) + 3}__door_{j}_0_{'identity' if j % 2 else 'rotated'}.json"))
     return raw, depth_root, hyp_root, fpaths
@@ -139,3 +143,91 @@ def test_batched_floor_renderer_writes_the_same_files_as_the_pairwise_one(tmp_pa
         render_dataset.render_pairs(1, "", "", "", "", None, ["rgb_texture"], "train", "0003")
     with pytest.raises(NotImplementedError):
         render_dataset.render_building_floor_pairs("", "", "", "", "0003", "floor_01", None, ["layout"])
+
+
+def test_fused_channel_order_follows_the_sorted_tile_names(tmp_path):
+    """The reference's dataset hands the verifier a pair's two tiles in FILE-NAME order (zind_data.py:110), which follows
+    the pano stems, not (i1, i2).  Here the partial-room numbers run against the pano ids, so for every hypothesis with
+    i1 < i2 the posed render is the SECOND image.  The fused path must feed exactly what the un-fused route feeds:
+    (a) lossless: tiles rendered through the facade, ordered by the dataset's own grouping rule
+        (zind_data.get_tuples_from_fpath_list on the names) -> same logits as the fused path, to the last bit;
+    (b) through JPEG files on disk and the dataset rule: logits agree within compression noise in the matched order, and
+        the other order is further away."""
+    from salve_amd import train_utils
+    from salve_amd.dataset import zind_data
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from salve_amd.pipeline import RenderVerifyPipeline
+    from salve_amd.utils import bev_rendering_utils as bru
+    from tests.test_gpu_dataset import config
+
+    raw, depth_root, hyp_root, fpaths = make_floor(tmp_path, reverse_rooms=True)
+    torch.manual_seed(3)
+    model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    dev = torch.device(DEV)
+    hyps = ingest.load_floor_hypotheses(str(hyp_root), "0003", "floor_01")
+    img_fpaths = ingest.floor_pano_fpaths(str(raw), "0003")
+    swap = hyps.swap(img_fpaths)
+    assert swap.tolist() == (hyps.i1 < hyps.i2).tolist() and swap.any() and not swap.all()
+    store = ingest.PanoStore(dev).load(img_fpaths, str(depth_root), "0003", np.concatenate([hyps.i1, hyps.i2]))
+    pipe = RenderVerifyPipeline(model, dev, chunk=4)
+    pipe.set_panos(store.rgb, store.depth)
+    prepared = pipe.prepare(hyps.table(store, img_fpaths))
+    fused = pipe.score(prepared).cpu()
+    assert pipe.valid_mask(prepared).all()
+    pipe.check()
+
+    args = config(str(tmp_path / "bev"), ["floor_rgb_texture"])
+    tf = train_utils.get_val_test_transform(args)
+    for j in range(len(hyps)):
+        label = "gt_alignment_approx" if hyps.label[j] else "incorrect_alignment"
+        for surface in ("floor", "ceiling"):
+            bru.generate_texture_maps_for_pair(img_fpaths, surface, hyps.fpaths[j], int(hyps.pair_idx[j]), label, str(tmp_path / "bev"), "0003",
+                                               "floor_01", str(depth_root), ["rgb_texture"], None, None)
+    names = hyps.tile_names(str(tmp_path / "bev"), img_fpaths)
+    worse = 0
+    for j in range(len(hyps)):
+        label_dir = tmp_path / "bev" / ("gt_alignment_approx" if hyps.label[j] else "incorrect_alignment") / "0003"
+        mine = [str(p) for p in label_dir.glob(f"pair_{int(hyps.pair_idx[j])}___*.jpg")]
+        (f1, f2, y), = zind_data.get_tuples_from_fpath_list(mine, int(hyps.label[j]), args)   # the dataset's ordering rule
+        assert (f1, f2) == names[j] and y == hyps.label[j]
+        # (a) lossless tiles in that order
+        a = SimpleNamespace(img_i1=img_fpaths[int(hyps.i1[j])], img_i2=img_fpaths[int(hyps.i2[j])],
+                            depth_i1=str(depth_root / "0003" / f"{Path(img_fpaths[int(hyps.i1[j])]).stem}.depth.png"),
+                            depth_i2=str(depth_root / "0003" / f"{Path(img_fpaths[int(hyps.i2[j])]).stem}.depth.png"),
+                            scale=0.001, crop_ratio=80 / 512, crop_z_range=[-float("inf"), -1.0])
+        S = Sim2.from_json(hyps.fpaths[j])
+        img1, img2 = bru.render_bev_pair(a, "0003", "floor_01", int(hyps.i1[j]), int(hyps.i2[j]), S, False)
+        first, second = (img2, img1) if swap[j] else (img1, img2)
+        x = tf(first, second)
+        with torch.no_grad():
+            lossless = model.cuda()(x[0][None], x[1][None], None, None, None, None).cpu()[0]
+        assert torch.equal(lossless, fused[j]), (j, lossless, fused[j])
+        # (b) the JPEG route
+        xj = tf(image_io.read_rgb(f1), image_io.read_rgb(f2))
+        with torch.no_grad():
+            matched = model(xj[0][None], xj[1][None], None, None, None, None).cpu()[0]
+            crossed = model(xj[1][None], xj[0][None], None, None, None, None).cpu()[0]
+        e_m, e_c = float((matched - fused[j]).abs().max()), float((crossed - fused[j]).abs().max())
+        assert e_m < 0.05 * max(1.0, float(fused[j].abs().max())), (j, e_m)
+        worse += e_c > e_m
+    assert worse >= len(hyps) - 1    # the crossed order is (almost always) further from the fused logits than the matched one
+
+
+def test_hypotheses_without_points_in_the_window_are_dropped(tmp_path):
+    """render_bev_image returns None when no point falls inside the BEV window (bev_rendering_utils.py:279-280), the pair
+    then writes no tile (:623-627) and never reaches scripts/test.py.  The fused route reports those hypotheses through the
+    in-window counts and writes no prediction for them."""
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+
+    raw, depth_root, hyp_root, _ = make_floor(tmp_path, n_hyp=6, far=(1, 4))
+    torch.manual_seed(3)
+    model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    m = ingest.score_floor(model, torch.device(DEV), str(raw), str(depth_root), str(hyp_root), str(tmp_path / "bev"), "0003", "floor_01",
+                           str(tmp_path / "preds"), batch_size=4, chunk=4)
+    assert m["num_hypotheses"] == 6 and m["num_dropped_no_points_in_window"] == 2
+    got = [json.load(open(f)) for f in sorted((tmp_path / "preds").glob("batch_*.json"))]
+    hyps = ingest.load_floor_hypotheses(str(hyp_root), "0003", "floor_01")
+    far_names = {Path(p).stem.split("__")[-1] for p in hyps.fpaths if "_1_0_" in Path(p).name or "_4_0_" in Path(p).name}
+    assert len(far_names) == 2
+    kept = sum((g["fp0"] for g in got), [])
+    assert len(kept) == 4 and not any(u in n for n in kept for u in far_names)

@@ -144,8 +144,36 @@ def test_bad_arguments_are_reported(setup):
     ras, panos, d_rgb, d_depth, hyp = setup
     import ctypes
 
-    st = ras.lib.salve_bev_render_batch(ctypes.byref(ras.cfg), None, None, 1, None, None, 1, None, None, None, None, None, None, None, 0, None)
+    st = ras.lib.salve_bev_render_batch(ctypes.byref(ras.cfg), None, None, 1, None, None, 1, None, None, None, None, None, None, None, None, 0, None)
     assert st == -1 and b"null" in ras.lib.salve_last_error()
     with pytest.raises(_lib.SalveHipError):
         ras.tiles(torch.zeros(1, device=ras.device, dtype=torch.int32), ras.upload_tile_jobs([0], [0], [0]), 1,
                   torch.zeros(1, device=ras.device), 7, 6)
+
+
+def test_cluttered_scene_renders_match_oracle():
+    """The second synthetic scene (box room + occluding furniture + a door opening: shadows, holes and a non-convex cloud
+    outline -- many more sites take the general star walk): final BEV images, floor and ceiling, bit-exact against the
+    oracle; the share of hard sites is printed next to the box room's."""
+    dev = torch.device("cuda:0")
+    ras = BevRasteriser(dev)
+    hyp = synthetic.make_hypotheses(6, 2, seed=3)
+    shares = {}
+    for scene in ("box", "cluttered"):
+        panos = [synthetic.make_pano(i, scene=scene) for i in range(2)]
+        d_rgb, d_depth = ras.upload_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
+        rows = [(int(hyp.i1[hi]), "floor" if hi % 2 == 0 else "ceiling", hyp.R[hi], hyp.t[hi], 1) for hi in range(6)]
+        h = pack_hypotheses([r[0] for r in rows], [0 if r[1] == "floor" else 1 for r in rows], np.stack([r[2] for r in rows]),
+                            np.stack([r[3] for r in rows]), [1] * len(rows))
+        bev, dbg = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), len(rows), debug=True)
+        torch.cuda.synchronize()
+        stats = dbg.stats.cpu().numpy()
+        shares[scene] = float(stats[:, 6].sum()) / float(stats[:, 0].sum())
+        assert (stats[:, 5] == 0).all()
+        if scene == "cluttered":
+            got = ras.export_u8(bev).cpu().numpy()
+            for k, (pi, surface, R, t, ap) in enumerate(rows):
+                res, _ = oracle_render(panos, pi, surface, R, t, ap)
+                assert np.array_equal(got[k], res["bev"]), f"cluttered scene, render {k} ({surface})"
+    print(f"hard-site share: box room {shares['box']:.4f}, cluttered room {shares['cluttered']:.4f}")
+    assert shares["cluttered"] > shares["box"]

@@ -10,23 +10,12 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 from oracle import resnet_oracle as ro  # noqa: E402
-from salve_amd import _lib  # noqa: E402
+from salve_amd import _lib, status  # noqa: E402
 from salve_amd.models import hip_resnet  # noqa: E402
 from salve_amd.models.early_fusion import EarlyFusionCEResnet  # noqa: E402
+from _helpers import randomise_bn  # noqa: E402
 
 DEV = "cuda:0"
-
-
-def randomise_bn(model, seed=0):
-    """Trained-looking BatchNorm statistics so that activations stay O(1) through the trunk."""
-    g = torch.Generator().manual_seed(seed)
-    for name, m in model.named_modules():
-        if isinstance(m, torch.nn.BatchNorm2d):
-            last = name.endswith("bn3") or (name.endswith("bn2") and model.resnet.block_kind == "basic")
-            m.weight.data = (0.25 if last else 1.0) * (0.6 + 0.4 * torch.rand(m.num_features, generator=g))
-            m.bias.data = 0.1 * torch.randn(m.num_features, generator=g)
-            m.running_mean.data = 0.1 * torch.randn(m.num_features, generator=g)
-            m.running_var.data = 0.6 + 0.8 * torch.rand(m.num_features, generator=g)
 
 
 def run_single_conv(w, b, x_nhwc, stride, pad, relu, res=None, kw_pad=0):
@@ -61,7 +50,7 @@ def run_single_conv(w, b, x_nhwc, stride, pad, relu, res=None, kw_pad=0):
     logits = torch.zeros((B, 2), dtype=torch.float32, device=DEV)
     xd = x_nhwc.to(DEV).contiguous()
     st = lib.salve_resnet_forward(h, ctypes.c_void_p(xd.data_ptr()), B, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                                  ws.numel(), None)
+                                  ws.numel(), None, None)
     torch.cuda.synchronize()
     assert st == 0, lib.salve_last_error()
     out = view[: B * Ho * Wo * Cout].float().cpu().reshape(B, Ho, Wo, Cout)
@@ -98,30 +87,77 @@ def test_conv_matches_torch(case):
     assert (err <= tol).all(), f"max err {err.max()} at |ref| {ref.abs().max()}"
 
 
+def tile_like_inputs(n, batch, seed=0):
+    """n fp32 [batch, 3, 224, 224] tensors with the value set of real tiles: (v - mean) / std of uint8 values."""
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randint(0, 256, (n, batch, 3, 224, 224), generator=g).float()
+    mean = torch.tensor([123.675, 116.28, 103.53]).view(1, 1, 3, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375]).view(1, 1, 3, 1, 1)
+    return list(((v - mean) / std).unbind(0))
+
+
 @pytest.mark.parametrize("num_layers,modalities,batch", [
     (50, ["floor_rgb_texture"], 5),
     (152, ["ceiling_rgb_texture", "floor_rgb_texture"], 2),
     (18, ["layout"], 3),
 ])
 def test_logits_match_oracle(num_layers, modalities, batch):
-    """north_star asks 1e-3 on the logits.  Activations and weights are fp16 (11 significand bits), accumulation fp32:
-    the bound here is 1e-3 of the logit scale (>= 1), and the measured error is printed."""
+    """north_star: classifier logits within 1e-3 of the reference's.  The oracle runs in fp32 on the SAME fp32 tiles the
+    product is given -- the fp16 rounding of the network input is part of the product's error, not removed from the
+    comparison -- and the bound is ABSOLUTE.  BatchNorm statistics are trained-looking (activations O(1) through the trunk,
+    logits O(0.1 - 1)): measured 2e-5 (ResNet-50), 2e-4 (ResNet-152, 12 channels), 5e-5 (ResNet-18)."""
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(num_layers, False, 2, SimpleNamespace(modalities=modalities))
     randomise_bn(model)
     model.eval()
     n = len(modalities) * 2
-    xs = [torch.randn(batch, 3, 224, 224) for _ in range(n)]
-    xs_b = [x.to(torch.float16).float() for x in xs]  # the network input is fp16 on the GPU side
+    xs = tile_like_inputs(n, batch)
     with torch.no_grad():
-        ref = ro.forward(model.state_dict(), num_layers, xs_b)
+        ref = ro.forward(model.state_dict(), num_layers, xs)
         pad = xs + [None] * (6 - n)
         got = model.to(DEV)(*[None if x is None else x.to(DEV) for x in pad]).cpu()
+    status.check(DEV, "test_logits_match_oracle")
+    err = float((got - ref).abs().max())
+    print(f"resnet{num_layers}: |logit| max {float(ref.abs().max()):.3f}, max abs err {err:.2e}")
+    assert err <= 1e-3
+
+
+@pytest.mark.parametrize("num_layers", [18, 50])
+def test_logits_with_default_batchnorm(num_layers):
+    """torchvision's DEFAULT BatchNorm statistics (weight 1, bias 0, mean 0, variance 1): the network has no normalisation,
+    activations and logits grow with depth (|logit| up to 5 for ResNet-18, 36 for ResNet-50 on tile-like input) and an
+    absolute 1e-3 is below the fp16 resolution of the stored activations (2^-11 relative per tensor).  Scale rule applied
+    here, and only here: |error| <= 1e-3 x max(1, max |logit|), i.e. 1e-3 RELATIVE to the logit magnitude once that exceeds
+    1.  Measured: 3.2e-3 at |logit| 5.4 (ResNet-18), 2.5e-2 at 35.8 (ResNet-50) -- 6e-4 and 7e-4 relative.  (This is the
+    case smoke() runs.  A released checkpoint has trained statistics: the absolute bound of test_logits_match_oracle.)"""
+    torch.manual_seed(0)
+    mods = ["layout"] if num_layers == 18 else ["floor_rgb_texture"]
+    model = EarlyFusionCEResnet(num_layers, False, 2, SimpleNamespace(modalities=mods)).eval()
+    xs = tile_like_inputs(2, 3, seed=1)
+    with torch.no_grad():
+        ref = ro.forward(model.state_dict(), num_layers, xs)
+        got = model.to(DEV)(xs[0].to(DEV), xs[1].to(DEV), None, None, None, None).cpu()
+    status.check(DEV, "test_logits_with_default_batchnorm")
     scale = max(1.0, float(ref.abs().max()))
     err = float((got - ref).abs().max())
-    print(f"resnet{num_layers}: logits scale {scale:.3f}, max abs err {err:.4f}")
+    print(f"resnet{num_layers} default BN: |logit| max {scale:.3f}, max abs err {err:.2e} ({err / scale:.1e} relative)")
     assert err <= 1e-3 * scale
-    assert (got.argmax(1) == ref.argmax(1)).all() or err < 1e-3
+    assert (got.argmax(1) == ref.argmax(1)).all()
+
+
+def test_activation_beyond_fp16_range_is_reported():
+    """ResNet-152 with default BatchNorm statistics has activations of 1e8: far beyond fp16 (65504).  The kernels saturate
+    the stored value AND raise SALVE_STATUS_FP16_RANGE in the device status word; the host turns it into an exception
+    instead of returning logits of a different network."""
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(152, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    xs = tile_like_inputs(2, 1, seed=2)
+    status.check(DEV, "before")
+    with torch.no_grad():
+        model.to(DEV)(xs[0].to(DEV), xs[1].to(DEV), None, None, None, None)
+    with pytest.raises(_lib.SalveHipError, match="fp16 range"):
+        status.check(DEV, "resnet152 default BN")
+    status.check(DEV, "the word is reset after it was raised")
 
 
 @pytest.mark.parametrize("stride,hw,cx,mid,cout", [(1, 56, 64, 64, 256), (2, 28, 256, 128, 512)])
@@ -151,7 +187,7 @@ def test_conv_with_projection_shortcut_as_second_source(stride, hw, cx, mid, cou
     ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
     xd = x_nhwc.to(DEV)
     logits = torch.zeros((B, 2), dtype=torch.float32, device=DEV)
-    st = lib.salve_resnet_forward(h, ctypes.c_void_p(xd.data_ptr()), B, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), None)
+    st = lib.salve_resnet_forward(h, ctypes.c_void_p(xd.data_ptr()), B, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), None, None)
     torch.cuda.synchronize()
     assert st == 0, lib.salve_last_error()
     per_buf = (need - 256) // 2 // 2                    # two buffers of 16-bit elements

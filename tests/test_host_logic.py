@@ -1,5 +1,6 @@
 """Host-side logic of salve_amd (no GPU): tables, packing, program builder, sharding, API mirrors."""
 
+import os
 import json
 import re
 from pathlib import Path
@@ -32,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.salve_hip_version() == 2
+    assert lib.salve_hip_version() == 3
     assert lib.salve_last_error() is not None
 
 
@@ -206,13 +207,66 @@ def test_checkpoint_loader_accepts_dataparallel_prefix(tmp_path):
         train_utils.load_model_checkpoint(str(tmp_path / "missing.pth"), dst, args)
 
 
-def test_install_as_salve_alias():
-    import salve_amd
+def _run_py(code: str, extra_path=None):
+    import subprocess
+    import sys as _sys
 
-    salve_amd.install_as_salve()
-    import salve.common.sim2 as s2
-    import salve.utils.bev_rendering_utils as b
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([str(ROOT)] + ([str(extra_path)] if extra_path else []))
+    r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
 
-    assert s2.Sim2 is Sim2 and callable(b.generate_texture_maps_for_pair)
-    assert b.bev_fname_from_img_fpath(58, "opening_0_0_rotated", "floor", "/x/floor_01_partial_room_01_pano_13.jpg") == \
-        "pair_58___opening_0_0_rotated_floor_rgb_floor_01_partial_room_01_pano_13.jpg"
+
+def test_install_as_salve_alias_when_no_salve_package_exists():
+    """No `salve` importable: the whole package is aliased (hot path only).  Run in a fresh interpreter."""
+    out = _run_py(
+        "import salve_amd; salve_amd.install_as_salve()\n"
+        "import salve.common.sim2 as s2, salve.utils.bev_rendering_utils as b\n"
+        "from salve_amd.common.sim2 import Sim2\n"
+        "assert s2.Sim2 is Sim2 and callable(b.generate_texture_maps_for_pair)\n"
+        "print(b.bev_fname_from_img_fpath(58, 'opening_0_0_rotated', 'floor', '/x/floor_01_partial_room_01_pano_13.jpg'))\n")
+    assert out.strip() == "pair_58___opening_0_0_rotated_floor_rgb_floor_01_partial_room_01_pano_13.jpg"
+
+
+def test_install_as_salve_overlays_a_real_package(tmp_path):
+    """A `salve` package is importable (here: a throw-away fake with the modules the reference's drivers import next to
+    the hot path -- scripts/test.py:17-23, scripts/render_dataset_bev.py:21-26): only the hot-path submodules are
+    replaced, everything else keeps resolving to the package's own files."""
+    pkg = tmp_path / "salve"
+    for d in ("", "utils", "common", "dataset", "models"):
+        (pkg / d).mkdir(parents=True, exist_ok=True)
+        (pkg / d / "__init__.py").write_text("")
+    (pkg / "utils" / "io.py").write_text("MARK = 'real io'\n")
+    (pkg / "utils" / "avg_meter.py").write_text("MARK = 'real avg_meter'\n")
+    (pkg / "utils" / "logger_utils.py").write_text("MARK = 'real logger'\n")
+    (pkg / "common" / "posegraph2d.py").write_text("MARK = 'real posegraph2d'\n")
+    (pkg / "dataset" / "hnet_prediction_loader.py").write_text("MARK = 'real loader'\n")
+    (pkg / "utils" / "bev_rendering_utils.py").write_text("MARK = 'the CPU renderer that must be replaced'\n")
+    (pkg / "models" / "early_fusion.py").write_text("MARK = 'the torchvision model that must be replaced'\n")
+    _run_py(
+        "import salve_amd; salve_amd.install_as_salve()\n"
+        "import salve, salve.utils.io, salve.utils.avg_meter, salve.utils.logger_utils\n"
+        "import salve.common.posegraph2d, salve.dataset.hnet_prediction_loader\n"
+        "assert salve is not salve_amd and salve.utils.io.MARK == 'real io' and salve.common.posegraph2d.MARK == 'real posegraph2d'\n"
+        "assert salve.dataset.hnet_prediction_loader.MARK == 'real loader' and salve.utils.avg_meter.MARK == 'real avg_meter'\n"
+        "import salve.utils.bev_rendering_utils as b, salve.models.early_fusion as ef, salve.common.sim2 as s2\n"
+        "from salve.utils import bev_rendering_utils as b2\n"
+        "import salve_amd.utils.bev_rendering_utils as mine, salve_amd.models.early_fusion as mine_ef, salve_amd.common.sim2 as mine_s2\n"
+        "assert b is mine and b2 is mine and ef is mine_ef and s2 is mine_s2 and not hasattr(b, 'MARK')\n"
+        "assert salve.utils.bev_rendering_utils is mine\n", extra_path=tmp_path)
+
+
+def test_cluttered_scene_is_a_box_room_with_occluders():
+    """synthetic.make_pano(scene="cluttered"): same walls as the box room of that index; furniture only ever shortens a ray,
+    the door opening only lengthens it; all returns stay inside the z-slice range of the reference's z-order ([-2, 2))."""
+    for idx in (0, 3):
+        box = synthetic.make_box_room_depth_mm(idx, 128, 256).astype(np.int64)
+        clut = synthetic.make_cluttered_room_depth_mm(idx, 128, 256).astype(np.int64)
+        assert clut.shape == box.shape and clut.min() > 300
+        shorter, longer = (clut < box).mean(), (clut > box).mean()
+        assert 0.02 < shorter < 0.6 and 0.0005 < longer < 0.1, (shorter, longer)
+        z = clut / 1000.0 * get_uni_sphere_xyz(128, 256)[..., 2]
+        assert z.min() >= synthetic.FLOOR_Z - 1e-3 and z.max() <= synthetic.CEILING_Z + 1e-3
+    assert np.array_equal(synthetic.make_pano(2, 64, 128)[1], synthetic.make_box_room_depth_mm(2, 64, 128))
+    assert np.array_equal(synthetic.make_pano(2, 64, 128, scene="cluttered")[0], synthetic.make_pano(2, 64, 128)[0])

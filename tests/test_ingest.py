@@ -53,8 +53,15 @@ def test_floor_work_list_order_and_names(tmp_path):
 
     panos = {i: f"/zind/0715/panos/floor_02_partial_room_{i % 7:02d}_pano_{i}.jpg" for i in (4, 5, 6, 7, 9, 10, 12, 38)}
     names = h.tile_names("/bev", panos)
-    assert names[1] == ("/bev/gt_alignment_approx/0715/pair_1___door_3_0_identity_floor_rgb_floor_02_partial_room_04_pano_4.jpg",
-                        "/bev/gt_alignment_approx/0715/pair_1___door_3_0_identity_floor_rgb_floor_02_partial_room_03_pano_38.jpg")
+    # (fp0, fp1) in FILE-NAME order, as the reference's dataset sorts a pair's tiles (zind_data.py:110): pano 38 lives in
+    # partial_room_03, pano 4 in partial_room_04, so the tile of i2 = 38 comes first although i1 = 4
+    assert names[1] == ("/bev/gt_alignment_approx/0715/pair_1___door_3_0_identity_floor_rgb_floor_02_partial_room_03_pano_38.jpg",
+                        "/bev/gt_alignment_approx/0715/pair_1___door_3_0_identity_floor_rgb_floor_02_partial_room_04_pano_4.jpg")
+    assert h.swap(panos).tolist() == [True, True, False, False, False]
+    # the order is lexicographic on the stem, not numeric on the pano id: pano_10 < pano_9 inside one partial room
+    same_room = {9: "/z/floor_02_partial_room_01_pano_9.jpg", 10: "/z/floor_02_partial_room_01_pano_10.jpg"}
+    assert h.swap({**panos, **same_room}).tolist()[4] is True
+    assert [Path(n).name.split("_pano_")[1] for n in h.tile_names("/bev", {**panos, **same_room})[4]] == ["10.jpg", "9.jpg"]
     assert names[2][0].startswith("/bev/incorrect_alignment/0715/pair_0___door_0_3_rotated_floor_rgb_")
     # the names parse back under the dataset rules
     from salve_amd.dataset import zind_data

@@ -98,7 +98,7 @@ if mode.startswith("op_"):
         with torch.cuda.stream(side):
             for _ in range(40):
                 lib.salve_resnet_forward(h, ctypes.c_void_p(xin.data_ptr()), B, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
-                                         ctypes.c_void_p(side.cuda_stream))
+                                         None, ctypes.c_void_p(side.cuda_stream))
         out, _ = ras.render(d_rgb, d_depth, hd, n)
         torch.cuda.synchronize()
         d = (out != ref).reshape(n, -1).any(1).nonzero().flatten().tolist()
