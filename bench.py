@@ -54,7 +54,8 @@ def _cores() -> int:
         phys = min(phys, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    return max(1, int(phys))
+    # a one-GPU box of this pool is a 16-core share of its host: more workers than that only oversubscribe it
+    return max(1, min(int(phys), int(os.environ.get("SALVE_CPU_BASELINE_CORES", "16"))))
 
 
 def _cpu_render_pair(i: int):
@@ -164,6 +165,7 @@ def main() -> None:
 
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(args.layers, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    synthetic.trained_looking_batchnorm(model)  # random-init weights of the named architecture; seeded trained-looking statistics
     pipe = RenderVerifyPipeline(model, dev, pano_hw=(PANO_H, PANO_W), chunk=args.chunk, overlap=not args.no_overlap, streams=args.streams)
     panos = [synthetic.make_pano(i, PANO_H, PANO_W, scene=args.scene) for i in range(args.panos)]
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))

@@ -134,16 +134,20 @@ class FloorHypotheses:
                                theta_deg=np.degrees(np.arctan2(self.R[:, 1, 0], self.R[:, 0, 0])).astype(np.float64),
                                swap=self.swap(img_fpaths))
 
-    def tile_names(self, bev_save_root: str, img_fpaths: Dict[int, str], surface_type: str = "floor") -> List[Tuple[str, str]]:
-        """(fp0, fp1) per hypothesis: the two tile paths generate_texture_maps_for_pair would write
-        (bev_rendering_utils.py:579-595), in the sorted order in which the reference's dataset hands them to the verifier and
-        scripts/test.py writes them to the prediction files (zind_data.py:110, 306-315)."""
+    def tile_paths(self, bev_save_root: str, img_fpaths: Dict[int, str], surface_type: str = "floor") -> List[Tuple[str, str]]:
+        """(path of pano i1's tile, path of pano i2's tile) per hypothesis: where generate_texture_maps_for_pair writes the
+        posed and the identity render (bev_rendering_utils.py:579-595, 629-630)."""
         out = []
         for j in range(len(self)):
             d = f"{bev_save_root}/{LABEL_TYPES[0] if self.label[j] else LABEL_TYPES[1]}/{self.building_id}"
-            out.append(tuple(sorted(f"{d}/{bev_fname_from_img_fpath(int(self.pair_idx[j]), self.pair_uuid[j], surface_type, img_fpaths[int(p)])}"
-                                    for p in (self.i1[j], self.i2[j]))))
+            out.append(tuple(f"{d}/{bev_fname_from_img_fpath(int(self.pair_idx[j]), self.pair_uuid[j], surface_type, img_fpaths[int(p)])}"
+                             for p in (self.i1[j], self.i2[j])))
         return out
+
+    def tile_names(self, bev_save_root: str, img_fpaths: Dict[int, str], surface_type: str = "floor") -> List[Tuple[str, str]]:
+        """(fp0, fp1) per hypothesis: the same two paths in the SORTED order in which the reference's dataset hands the tiles
+        to the verifier and scripts/test.py writes them to the prediction files (zind_data.py:110, 306-315)."""
+        return [tuple(sorted(pair)) for pair in self.tile_paths(bev_save_root, img_fpaths, surface_type)]
 
 
 def load_floor_hypotheses(hypotheses_save_root: str, building_id: str, floor_id: str) -> FloorHypotheses:

@@ -48,7 +48,7 @@ def render_building_floor_pairs(depth_save_root: str, bev_save_root: str, hypoth
     if len(hyps) == 0:
         return 0
     img_fpaths = ingest.floor_pano_fpaths(raw_dataset_dir, building_id)
-    names = {s: hyps.tile_names(bev_save_root, img_fpaths, s) for s in SURFACE_TYPES}
+    names = {s: hyps.tile_paths(bev_save_root, img_fpaths, s) for s in SURFACE_TYPES}  # (tile of i1, tile of i2)
     todo = [(j, s) for j in range(len(hyps)) for s in SURFACE_TYPES
             if not (Path(names[s][j][0]).exists() and Path(names[s][j][1]).exists())]   # both exist: skip (idempotent restart)
     if not todo:

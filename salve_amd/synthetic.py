@@ -174,3 +174,20 @@ def make_hypotheses(n: int, num_panos: int, seed: int = 0) -> HypothesisTable:
     return HypothesisTable(
         i1.astype(np.int32), i2.astype(np.int32), R.astype(np.float32), t.astype(np.float32), theta
     )
+
+
+def trained_looking_batchnorm(model, seed: int = 0) -> None:
+    """Give a freshly initialised verifier BatchNorm statistics that look like a trained network's, so that activations stay
+    O(1) through the trunk.  (torchvision's initialisation -- weight 1, bias 0, mean 0, variance 1 -- is no normalisation
+    at all: activations grow with depth, up to 1e8 in ResNet-152.  No checkpoint is available offline, so tests, smoke() and
+    the benchmark use these seeded statistics; the last BatchNorm of every block is scaled down the way training leaves it.)"""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            last = name.endswith("bn3") or (name.endswith("bn2") and model.resnet.block_kind == "basic")
+            m.weight.data = (0.25 if last else 1.0) * (0.6 + 0.4 * torch.rand(m.num_features, generator=g))
+            m.bias.data = 0.1 * torch.randn(m.num_features, generator=g)
+            m.running_mean.data = 0.1 * torch.randn(m.num_features, generator=g)
+            m.running_var.data = 0.6 + 0.8 * torch.rand(m.num_features, generator=g)

@@ -4,16 +4,10 @@ import torch
 
 
 def randomise_bn(model, seed=0):
-    """Trained-looking BatchNorm statistics so that activations stay O(1) through the trunk (a freshly initialised
-    network with identity BatchNorm has no normalisation at all: its activations grow with depth)."""
-    g = torch.Generator().manual_seed(seed)
-    for name, m in model.named_modules():
-        if isinstance(m, torch.nn.BatchNorm2d):
-            last = name.endswith("bn3") or (name.endswith("bn2") and model.resnet.block_kind == "basic")
-            m.weight.data = (0.25 if last else 1.0) * (0.6 + 0.4 * torch.rand(m.num_features, generator=g))
-            m.bias.data = 0.1 * torch.randn(m.num_features, generator=g)
-            m.running_mean.data = 0.1 * torch.randn(m.num_features, generator=g)
-            m.running_var.data = 0.6 + 0.8 * torch.rand(m.num_features, generator=g)
+    """Trained-looking BatchNorm statistics (salve_amd.synthetic.trained_looking_batchnorm)."""
+    from salve_amd.synthetic import trained_looking_batchnorm
+
+    trained_looking_batchnorm(model, seed)
 
 
 def oracle_floor_render(args):
