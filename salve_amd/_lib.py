@@ -11,7 +11,10 @@ from pathlib import Path
 
 import numpy as np
 
-LIB_PATH = Path(__file__).resolve().parent / "libsalve_hip.so"
+import os
+
+# SALVE_HIP_LIB: development override (ablation builds of tools/build_ablations.sh); the product loads the in-tree library
+LIB_PATH = Path(os.environ.get("SALVE_HIP_LIB") or (Path(__file__).resolve().parent / "libsalve_hip.so"))
 
 SALVE_OK = 0
 TILE_F32_NCHW = 0

@@ -42,6 +42,7 @@ struct ConvArgs {
     const uint16_t* in2;
     int Hi2, Wi2, Cin2, stride2, nkt1;
     int32_t* status;        // device status word (salve_hip.h) or nullptr
+    int KW, cin_log2;       // conv_wide_kernel: padded kernel width, log2(Cin) (Cin is a power of two there)
 };
 
 // Activations and weights are IEEE half precision (fp16: 11 significand bits; the MFMA rate is that of bf16).  With bf16
@@ -250,6 +251,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
             *reinterpret_cast<uint4*>(p.out + (long long)m * p.Cout + n0 + ch * 8) = *reinterpret_cast<const uint4*>(Cs + r * LDC + ch * 8);
     }
 }
+
+#include "conv_wide.h"
 
 // 3x3 / stride 2 / pad 1 max-pool on NHWC fp16, 8 channels (16 bytes) per thread.
 __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B,
@@ -664,7 +667,27 @@ struct ResnetHandle {
     int n_bufs = 0;
     int num_layers = 0, in_channels = 0, ncls = 0;
     std::vector<int> fused;  // per op: 1 = this op and the next two form a bottleneck block run by bottleneck_kernel
+    std::vector<int> wide;   // per op: 0 = conv_igemm_kernel, else a conv_wide_kernel configuration (WIDE_*)
 };
+
+// Alternative convolution kernels (conv_wide.h), selected with SALVE_CONV_WIDE=d|e|f when a handle is created.  They are
+// bit-identical to conv_igemm_kernel (same k order, same fp32 accumulation; tests/test_gpu_verifier.py) and were measured
+// per shape on MI355X ("wide tiles"): none beats the 128 x 128 kernel at four workgroups per CU by more
+// than a few per cent on any ResNet shape, so the default is OFF -- they stay selectable because the measurements and the
+// ablations that explain them are part of the design record.
+enum { WIDE_OFF = 0, WIDE_256_K64_S2 = 4, WIDE_128_K64_S1 = 5, WIDE_PC_128 = 6 };
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static int choose_wide(const salve_resnet_op_t& o, int force) {
+    if (o.op != SALVE_OP_CONV || force == WIDE_OFF) return WIDE_OFF;
+    const bool pointwise = o.KH == 1 && o.KW == 1 && o.stride == 1 && o.pad == 0;
+    const int K = o.KH * o.KW * o.Cin + (o.in2_buf != SALVE_NO_BUF ? o.Cin2 : 0);
+    if (!pointwise && (!is_pow2(o.Cin) || o.Cin < 64)) return WIDE_OFF;   // the stem keeps its table-driven gather
+    if (K < 128 || K % 64 != 0) return WIDE_OFF;
+    if (force == WIDE_256_K64_S2) return o.Cout % 256 == 0 ? force : WIDE_OFF;
+    return o.Cout % 128 == 0 ? force : WIDE_OFF;
+}
 
 bool check_op(const salve_resnet_op_t& o) {
     if (o.op == SALVE_OP_CONV) {
@@ -713,6 +736,12 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
         } else {
             h->ncls = o.Cout;
         }
+    }
+    h->wide.assign(h->ops.size(), 0);
+    {
+        const char* e = getenv("SALVE_CONV_WIDE");   // unset: off; d, e, f: that alternative kernel wherever the shape allows it
+        const int mode = !e ? WIDE_OFF : (e[0] == 'd' ? WIDE_256_K64_S2 : (e[0] == 'e' ? WIDE_128_K64_S1 : (e[0] == 'f' ? WIDE_PC_128 : WIDE_OFF)));
+        for (size_t i = 0; i < h->ops.size(); i++) h->wide[i] = choose_wide(h->ops[i], mode);
     }
     h->fused.assign(h->ops.size(), 0);
     {
@@ -835,6 +864,32 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             const long long M = (long long)batch * o.Ho * o.Wo;
             if (M > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
             a.M = (int)M;
+            a.KW = o.KW;
+            a.cin_log2 = 0;
+            while ((1 << a.cin_log2) < o.Cin) a.cin_log2++;
+            if (h->wide[oi] != WIDE_OFF) {
+                const int cfg = h->wide[oi];
+                const int bn = cfg == WIDE_256_K64_S2 ? 256 : 128;
+                a.m_tiles = (int)((M + WIDE_BM - 1) / WIDE_BM);
+                a.n_tiles = o.Cout / bn;
+                const unsigned grid = (unsigned)(((a.m_tiles + 7) / 8) * 8 * a.n_tiles);
+                const bool pw = o.KH == 1 && o.KW == 1 && o.stride == 1 && o.pad == 0;
+#define WIDE_LAUNCH(BN_, KS_, NS_)                                                                                                  \
+    {                                                                                                                               \
+        if (src2) hipLaunchKernelGGL((conv_wide_kernel<BN_, KS_, NS_, true, true>), dim3(grid), dim3(WIDE_THREADS), 0, s, a);       \
+        else if (pw) hipLaunchKernelGGL((conv_wide_kernel<BN_, KS_, NS_, true, false>), dim3(grid), dim3(WIDE_THREADS), 0, s, a);   \
+        else hipLaunchKernelGGL((conv_wide_kernel<BN_, KS_, NS_, false, false>), dim3(grid), dim3(WIDE_THREADS), 0, s, a);          \
+    }
+                if (cfg == WIDE_PC_128) {
+                    if (src2) hipLaunchKernelGGL((conv_pc_kernel<true, true>), dim3(grid), dim3(PC_THREADS), 0, s, a);
+                    else if (pw) hipLaunchKernelGGL((conv_pc_kernel<true, false>), dim3(grid), dim3(PC_THREADS), 0, s, a);
+                    else hipLaunchKernelGGL((conv_pc_kernel<false, false>), dim3(grid), dim3(PC_THREADS), 0, s, a);
+                } else if (cfg == WIDE_256_K64_S2) WIDE_LAUNCH(256, 64, 2)
+                else WIDE_LAUNCH(128, 64, 1)
+#undef WIDE_LAUNCH
+                SALVE_HIP_CHECK(hipGetLastError());
+                continue;
+            }
             a.m_tiles = (int)((M + BM - 1) / BM);
             const int bn = (o.Cout % 128 == 0) ? 128 : 64;
             a.n_tiles = o.Cout / bn;

@@ -221,6 +221,29 @@ def test_fused_bottleneck_is_bit_identical_to_three_kernels(monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("cfg", ["d", "e", "f"])
+def test_alternative_convolution_kernels_are_bit_identical(monkeypatch, cfg):
+    """SALVE_CONV_WIDE = d | e | f routes the convolutions through the wide-tile / split-role kernels of conv_wide.h where the
+    shape allows it (read when the handle is created).  Same k order and fp32 accumulation as conv_igemm_kernel: the logits
+    of ResNet-50 must agree bit for bit with the default kernels'."""
+    torch.manual_seed(6)
+    model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"]))
+    randomise_bn(model, seed=6)
+    model.eval()
+    x = torch.randn(5, 224, 224, 8).to(torch.float16).to(DEV)
+    x[..., 6:] = 0
+    outs = []
+    for v in (None, cfg):
+        if v is None:
+            monkeypatch.delenv("SALVE_CONV_WIDE", raising=False)
+        else:
+            monkeypatch.setenv("SALVE_CONV_WIDE", v)
+        eng = hip_resnet.HipResNet(model.state_dict(), 50, torch.device(DEV))
+        outs.append(eng.forward_nhwc(x).clone())
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_forward_refuses_cpu_and_bad_modalities():
     model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["layout"])).eval()
     x = torch.zeros(1, 3, 224, 224)

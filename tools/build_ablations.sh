@@ -1,0 +1,11 @@
+#!/bin/bash
+# Development: ablation builds of the library (one -D flag each) into tools/_abl/ (git-ignored *.so; they travel with gpurun).
+set -e
+cd "$(dirname "$0")/../salve_amd/csrc"
+mkdir -p ../../tools/_abl
+for tag in NO_MFMA NO_LOADS NO_DSREAD; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DWIDE_$tag -o ../../tools/_abl/libsalve_$tag.so *.hip &
+done
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DWIDE_NO_LOADS -DWIDE_NO_DSREAD -o ../../tools/_abl/libsalve_MFMA_ONLY.so *.hip &
+wait
+ls -la ../../tools/_abl/
