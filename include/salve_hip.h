@@ -34,7 +34,8 @@ typedef enum {
     SALVE_ERR_WORKSPACE = -4
 } salve_status_t;
 
-#define SALVE_HIP_ABI_VERSION 3  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter */
+#define SALVE_HIP_ABI_VERSION 3  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter,
+                                     salve_bev_workspace_init */
 
 /* Device status word: an optional device int32 the caller zeroes once and passes to the launches below.  Kernels OR bits
  * into it when something went wrong that an int return value cannot report (the launch is asynchronous); the caller
@@ -87,6 +88,12 @@ typedef struct {
 
 /* Bytes of device workspace salve_bev_render_batch needs for n renders (0 on bad config). */
 size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n);
+/* Must be called ONCE on a freshly allocated workspace before its first use (and again if the buffer was written by anything
+ * else): zeroes the z-order key images of every render the buffer can hold.  The layout inside the buffer is a function of
+ * `workspace_bytes` -- pass the SAME size to every call that uses the buffer; launches of any n up to its capacity share it.  The render calls do not clear them
+ * per launch -- 1 MB of writes per render -- because the densify kernel leaves every key cell it read zeroed again; a
+ * scatter whose densify never ran (an error in between) leaves the workspace dirty: initialise it again. */
+int salve_bev_workspace_init(const salve_bev_config_t* cfg, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Render n BEV texture maps.

@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "salve_hip_version",
     "salve_last_error",
     "salve_bev_workspace_bytes",
+    "salve_bev_workspace_init",
     "salve_bev_render_batch",
     "salve_bev_scatter",
     "salve_bev_densify",
@@ -91,6 +92,8 @@ def load() -> ctypes.CDLL:
     lib.salve_last_error.restype = ctypes.c_char_p
     lib.salve_bev_workspace_bytes.argtypes = [ctypes.POINTER(BevConfig), i32]
     lib.salve_bev_workspace_bytes.restype = sz
+    lib.salve_bev_workspace_init.argtypes = [ctypes.POINTER(BevConfig), i32, vp, sz, vp]
+    lib.salve_bev_workspace_init.restype = ctypes.c_int
     lib.salve_bev_render_batch.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.salve_bev_render_batch.restype = ctypes.c_int
     lib.salve_bev_scatter.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, sz, vp]

@@ -66,94 +66,141 @@ struct DevCfg {
     int dbg_flags;  // development only: 1 = skip the star phase, 2 = walk stars but do not rasterise
 };
 
+// What the densify kernel needs of the configuration: six integers (the full DevCfg with its 19 doubles, passed by
+// value, cost the kernel 101 SGPR spills).
+struct DensifyCfg {
+    int H, W, wpr, mask_half, out_flags, dbg_flags;
+};
+
 // ------------------------------------------------------------------------------------------------ scatter
+// Per-render bounding box of the occupied key cells, kept as four maxima so that one memset(0) initialises it:
+// [0] max(x + 1)  [1] max(y + 1)  [2] max(W - x)  [3] max(H - y);  [0] == 0: no cell.
 __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
     DevCfg c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, const double* __restrict__ sphere,
     const salve_bev_hyp_t* __restrict__ hyps, uint32_t* __restrict__ keys, const uint8_t** __restrict__ colour_src,
-    int16_t* __restrict__ dbg_xy, int32_t* __restrict__ in_window, int pass) {
+    int16_t* __restrict__ dbg_xy, int32_t* __restrict__ in_window, int32_t* __restrict__ bbox, int pass) {
     const int rid = blockIdx.y;
     const salve_bev_hyp_t h = hyps[rid];
     // where the densify kernel finds the colour of point index i of this render: colour_src[rid] + 3 i
     if (blockIdx.x == 0 && threadIdx.x == 0) colour_src[rid] = rgb + ((size_t)h.pano_idx * c.pano_h + c.crop_rows) * c.pano_w * 3;
     const int p0 = (blockIdx.x * SCATTER_THREADS + threadIdx.x) * PTS_PER_THREAD;  // first point (cropped raster)
-    __shared__ int block_in_window;
-    const bool counting = in_window != nullptr && pass == 0;   // (uniform)
-    if (counting) {
-        if (threadIdx.x == 0) block_in_window = 0;
+    __shared__ int block_acc[5];   // [0] points inside the window, [1..4] bounding box maxima
+    if (pass == 0) {               // (uniform)
+        if (threadIdx.x < 5) block_acc[threadIdx.x] = 0;
         __syncthreads();
     }
     int my_in_window = 0;
+    int cell[PTS_PER_THREAD];      // key-image cell of each point, -1: none
+    uint32_t key[PTS_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PTS_PER_THREAD; k++) { cell[k] = -1; key[k] = 0u; }
+    int bx1 = 0, by1 = 0, bx0 = 0, by0 = 0;
     if (p0 < c.npts) {
-    const int v = p0 / c.pano_w + c.crop_rows;
-    const int u0 = p0 % c.pano_w;  // pano_w is a multiple of 4: the four points share the row
-    const size_t pix = ((size_t)h.pano_idx * c.pano_h + v) * c.pano_w + u0;
+        const int v = p0 / c.pano_w + c.crop_rows;
+        const int u0 = p0 % c.pano_w;  // pano_w is a multiple of 4: the four points share the row
+        const size_t pix = ((size_t)h.pano_idx * c.pano_h + v) * c.pano_w + u0;
 
-    const double* rr = sphere;
-    const double* zd = sphere + c.pano_h;
-    const double* ct = sphere + 2 * c.pano_h;
-    const double* st = ct + c.pano_w;
-    const double rv = rr[v], zv = zd[v];
+        const double* rr = sphere;
+        const double* zd = sphere + c.pano_h;
+        const double* ct = sphere + 2 * c.pano_h;
+        const double* st = ct + c.pano_w;
+        const double rv = rr[v], zv = zd[v];
 
-    const uint2 dq = *reinterpret_cast<const uint2*>(depth + pix);  // 4 x u16
-    const uint32_t dep[4] = {dq.x & 0xFFFFu, dq.x >> 16, dq.y & 0xFFFFu, dq.y >> 16};
+        const uint2 dq = *reinterpret_cast<const uint2*>(depth + pix);  // 4 x u16
+        const uint32_t dep[4] = {dq.x & 0xFFFFu, dq.x >> 16, dq.y & 0xFFFFu, dq.y >> 16};
 
-    const double zlo = c.zlo[h.surface], zhi = c.zhi[h.surface];
-    const double R00 = (double)h.R[0], R01 = (double)h.R[1], R10 = (double)h.R[2], R11 = (double)h.R[3];
-    const double tx = (double)(h.t[0] * 1.5f), ty = (double)(h.t[1] * 1.5f);  // float32 product, then widened
-    uint32_t* kimg = keys + (size_t)rid * c.H * c.W;
+        const double zlo = c.zlo[h.surface], zhi = c.zhi[h.surface];
+        const double R00 = (double)h.R[0], R01 = (double)h.R[1], R10 = (double)h.R[2], R11 = (double)h.R[3];
+        const double tx = (double)(h.t[0] * 1.5f), ty = (double)(h.t[1] * 1.5f);  // float32 product, then widened
 
 #pragma unroll
-    for (int k = 0; k < PTS_PER_THREAD; k++) {
-        const int u = u0 + k;
-        const float d32 = (float)dep[k] * c.depth_scale;
-        const double d = (double)d32;
-        const double z = d * zv;
-        int ix = -1, iy = -1;
-        if (z > zlo && z <= zhi) {
-            const double x = d * (rv * ct[u]);
-            const double y = d * (rv * st[u]);
-            // xy @ rotmat2d(-90).T, evaluated like OpenBLAS' FMA dgemm kernel: fma(y, R01, x*R00)
-            double x1 = fma(y, c.rp01, x * c.rp00);
-            double y1 = fma(y, c.rp11, x * c.rp10);
-            if (h.apply_pose) {
-                const double x2 = fma(y1, R01, x1 * R00) + tx;
-                const double y2 = fma(y1, R11, x1 * R10) + ty;
-                x1 = x2;
-                y1 = y2;
-            }
-            if (c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax) {
-                // bevimg_Sim2_world.transform_from: (p @ I.T + t) * s, then np.round (half to even)
-                const double fx = rint((fma(y1, 0.0, x1 * 1.0) + c.tx) * c.scale);
-                const double fy = rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
-                ix = (int)fx;
-                iy = (int)fy;
-                my_in_window++;
-                const double zs = floor(z) - c.zmin;  // unit slices from an integer z_min: exact
-                if (zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H) {
-                    const uint32_t key = ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | (uint32_t)(p0 + k);
-                    uint32_t* cell = kimg + (size_t)iy * c.W + ix;
-                    if (pass == 0) {
-                        *cell = key;                                  // racy plain store: SOME contender of the pixel lands
-                    } else if (key > *cell) {
-                        atomicMax(cell, key);                         // rare: only contenders above what landed
+        for (int k = 0; k < PTS_PER_THREAD; k++) {
+            const int u = u0 + k;
+            const float d32 = (float)dep[k] * c.depth_scale;
+            const double d = (double)d32;
+            const double z = d * zv;
+            int ix = -1, iy = -1;
+            if (z > zlo && z <= zhi) {
+                const double x = d * (rv * ct[u]);
+                const double y = d * (rv * st[u]);
+                // xy @ rotmat2d(-90).T, evaluated like OpenBLAS' FMA dgemm kernel: fma(y, R01, x*R00)
+                double x1 = fma(y, c.rp01, x * c.rp00);
+                double y1 = fma(y, c.rp11, x * c.rp10);
+                if (h.apply_pose) {
+                    const double x2 = fma(y1, R01, x1 * R00) + tx;
+                    const double y2 = fma(y1, R11, x1 * R10) + ty;
+                    x1 = x2;
+                    y1 = y2;
+                }
+                if (c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax) {
+                    // bevimg_Sim2_world.transform_from: (p @ I.T + t) * s, then np.round (half to even)
+                    const double fx = rint((fma(y1, 0.0, x1 * 1.0) + c.tx) * c.scale);
+                    const double fy = rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
+                    ix = (int)fx;
+                    iy = (int)fy;
+                    my_in_window++;
+                    const double zs = floor(z) - c.zmin;  // unit slices from an integer z_min: exact
+                    if (zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H) {
+                        key[k] = ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | (uint32_t)(p0 + k);
+                        cell[k] = iy * c.W + ix;
+                        bx1 = max(bx1, ix + 1); by1 = max(by1, iy + 1); bx0 = max(bx0, c.W - ix); by0 = max(by0, c.H - iy);
                     }
                 }
             }
-        }
-        if (dbg_xy && pass == 0) {
-            int16_t* o = dbg_xy + ((size_t)rid * c.npts + p0 + k) * 2;
-            o[0] = (int16_t)ix;
-            o[1] = (int16_t)iy;
+            if (dbg_xy && pass == 0) {
+                int16_t* o = dbg_xy + ((size_t)rid * c.npts + p0 + k) * 2;
+                o[0] = (int16_t)ix;
+                o[1] = (int16_t)iy;
+            }
         }
     }
+    // Runs: consecutive panorama pixels land on the same or on neighbouring cells.  A point whose SUCCESSOR in raster order
+    // hits the same cell with a larger key can never be the cell's maximum: it neither stores nor checks (40 % of the
+    // in-window points of a floor render).  The successor of a thread's last point is the first point of the next lane.
+    const int lane = threadIdx.x & 63;
+    const int ncell = __shfl_down(cell[0], 1);
+    const uint32_t nkey = __shfl_down(key[0], 1);
+    bool live[PTS_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PTS_PER_THREAD; k++) {
+        const int sc = k + 1 < PTS_PER_THREAD ? cell[(k + 1) % PTS_PER_THREAD] : (lane < 63 ? ncell : -1);
+        const uint32_t sk = k + 1 < PTS_PER_THREAD ? key[(k + 1) % PTS_PER_THREAD] : nkey;
+        live[k] = cell[k] >= 0 && !(sc == cell[k] && sk > key[k]);
     }
-    if (counting) {
-        // points inside the window (prune_to_2d_bbox, :38-45): one LDS add per wave, one global atomic per workgroup --
-        // a device-scope atomic per point on ONE address per render would serialise at the memory side
-        for (int off = 32; off >= 1; off >>= 1) my_in_window += __shfl_xor(my_in_window, off);
-        if ((threadIdx.x & 63) == 0 && my_in_window) atomicAdd(&block_in_window, my_in_window);
+    uint32_t* kimg = keys + (size_t)rid * c.H * c.W;
+    if (pass == 0) {
+#pragma unroll
+        for (int k = 0; k < PTS_PER_THREAD; k++)
+            if (live[k]) kimg[cell[k]] = key[k];           // racy plain store: SOME contender of the pixel lands
+    } else {
+        uint32_t landed[PTS_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < PTS_PER_THREAD; k++) landed[k] = live[k] ? kimg[cell[k]] : 0xFFFFFFFFu;   // all four loads in flight
+#pragma unroll
+        for (int k = 0; k < PTS_PER_THREAD; k++)
+            if (key[k] > landed[k]) atomicMax(kimg + cell[k], key[k]);   // rare: only contenders above what landed
+    }
+    if (pass == 0) {
+        // Per render: points inside the window (prune_to_2d_bbox, :38-45) and the bounding box of the occupied cells -- one
+        // LDS atomic per wave and value, one global atomic per workgroup and value: a device-scope atomic per point on ONE
+        // address per render would serialise at the memory side.
+        for (int off = 32; off >= 1; off >>= 1) {
+            my_in_window += __shfl_xor(my_in_window, off);
+            bx1 = max(bx1, __shfl_xor(bx1, off)); by1 = max(by1, __shfl_xor(by1, off));
+            bx0 = max(bx0, __shfl_xor(bx0, off)); by0 = max(by0, __shfl_xor(by0, off));
+        }
+        if (lane == 0) {
+            if (my_in_window) atomicAdd(&block_acc[0], my_in_window);
+            if (bx1) { atomicMax(&block_acc[1], bx1); atomicMax(&block_acc[2], by1); atomicMax(&block_acc[3], bx0); atomicMax(&block_acc[4], by0); }
+        }
         __syncthreads();
-        if (threadIdx.x == 0 && block_in_window) atomicAdd(in_window + rid, block_in_window);
+        if (threadIdx.x == 0) {
+            if (in_window && block_acc[0]) atomicAdd(in_window + rid, block_acc[0]);
+            if (block_acc[1]) {
+                atomicMax(bbox + 4 * rid + 0, block_acc[1]); atomicMax(bbox + 4 * rid + 1, block_acc[2]);
+                atomicMax(bbox + 4 * rid + 2, block_acc[3]); atomicMax(bbox + 4 * rid + 3, block_acc[4]);
+            }
+        }
     }
 }
 
@@ -162,9 +209,12 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
 __global__ __launch_bounds__(256) void bev_scatter_points_kernel(DevCfg c, const double* __restrict__ xyz,
                                                                  const uint8_t* __restrict__ rgb, int npts,
                                                                  uint32_t* __restrict__ kimg, const uint8_t** __restrict__ colour_src,
-                                                                 int* __restrict__ n_in_window) {
+                                                                 int* __restrict__ n_in_window, int32_t* __restrict__ bbox) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) colour_src[0] = rgb;
+    if (i == 0) {
+        colour_src[0] = rgb;
+        bbox[0] = c.W; bbox[1] = c.H; bbox[2] = c.W; bbox[3] = c.H;   // the whole image (no per-block aggregation here)
+    }
     if (i >= npts) return;
     const double x1 = xyz[3 * (size_t)i], y1 = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
     if (!(c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax)) return;
@@ -320,7 +370,7 @@ static int ensure_star_table() {
 }
 
 __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
-    DevCfg c, const uint32_t* __restrict__ keys_all, const uint8_t* const* __restrict__ colour_src, uint32_t* __restrict__ bev_all,
+    DensifyCfg c, uint32_t* __restrict__ keys_all, const int32_t* __restrict__ bbox_all, const uint8_t* const* __restrict__ colour_src, uint32_t* __restrict__ bev_all,
     uint32_t* __restrict__ sitelist_all, uint32_t* __restrict__ hardlist_all, unsigned long long* __restrict__ triq_all,
     uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats, int16_t* __restrict__ dbg_aux, int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -334,7 +384,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     unsigned long long* tri_cache = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(scal + 16) + 7) & ~(uintptr_t)7);  // SD_CACHE_SIZE entries
 
     const int rid = blockIdx.x;
-    const uint32_t* keys = keys_all + (size_t)rid * H * W;
+    uint32_t* keys = keys_all + (size_t)rid * H * W;
     const uint8_t* colours = colour_src[rid];
     const int flip = (c.out_flags & 1) ? -1 : H - 1;
     uint32_t* bev = bev_all + (size_t)rid * H * W;
@@ -356,17 +406,32 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     //      `msk` receives the horizontally dilated "non-empty" bits (uint8 channel product wraps mod 256).
     const int nseg = (W + 63) >> 6;
     constexpr int ROW_SEGS = 8;  // rows of up to 512 pixels are fetched whole: all key loads, then all colour gathers, in flight together
+    // Bounding box of the occupied key cells (the scatter's block-aggregated maxima): rows and 64-pixel segments outside it
+    // hold no key -- they are not read, only their part of the output image is written (zeros).  The key cells that ARE read
+    // are zeroed again right here, whole segments with a coalesced store, so that the next scatter into this workspace
+    // finds a clean key image without a 1 MB memset per render.
+    const int bb_x1 = bbox_all[4 * rid + 0], bb_y1 = bbox_all[4 * rid + 1], bb_x0 = bbox_all[4 * rid + 2], bb_y0 = bbox_all[4 * rid + 3];
+    const bool bb_any = bb_x1 > 0;
+    const int y_lo = bb_any ? H - bb_y0 : 0, y_hi = bb_any ? bb_y1 - 1 : -1;
+    const int seg_lo = bb_any ? (W - bb_x0) >> 6 : 0, seg_hi = bb_any ? (bb_x1 - 1) >> 6 : -1;
     for (int y = wave; y < H; y += nwaves) {
         int lo = W, hi = -1;
         unsigned long long ne_prev = 0, ne_cur = 0;
         uint32_t row_key[ROW_SEGS], row_col[ROW_SEGS];
         const bool whole_row = nseg <= ROW_SEGS;
+        const bool row_in = y >= y_lo && y <= y_hi;
+        if (!row_in) {   // (wave-uniform) nothing to read: empty bitmap rows, zero output row
+            for (int x = lane; x < W; x += 64) bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = 0u;
+            for (int w = lane; w < wpr; w += 64) { occ[y * wpr + w] = 0u; msk[y * wpr + w] = 0u; }
+            if (lane == 0) { rmin[y] = (int16_t)W; rmax[y] = (int16_t)-1; }
+            continue;
+        }
         if (whole_row) {
             // Two memory round trips per row instead of two per 64-pixel segment: this phase is nothing but latency.
 #pragma unroll
             for (int sg = 0; sg < ROW_SEGS; sg++) {
                 const int x = (sg << 6) + lane;
-                row_key[sg] = (sg < nseg && x < W) ? load_key(keys + (size_t)y * W + x) : 0u;
+                row_key[sg] = (sg >= seg_lo && sg <= seg_hi && x < W) ? load_key(keys + (size_t)y * W + x) : 0u;
             }
 #pragma unroll
             for (int sg = 0; sg < ROW_SEGS; sg++) {
@@ -376,6 +441,11 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                     col = (uint32_t)cs[0] | ((uint32_t)cs[1] << 8) | ((uint32_t)cs[2] << 16);
                 }
                 row_col[sg] = col;
+            }
+#pragma unroll
+            for (int sg = 0; sg < ROW_SEGS; sg++) {
+                const int x = (sg << 6) + lane;
+                if (__ballot(row_key[sg] != 0u) != 0ull && x < W) keys[(size_t)y * W + x] = 0u;
             }
         }
         for (int seg = 0; seg <= nseg; seg++) {
@@ -387,11 +457,12 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                     key = row_key[seg & (ROW_SEGS - 1)];
                     col = row_col[seg & (ROW_SEGS - 1)];
                 } else {
-                    if (x < W) key = load_key(keys + (size_t)y * W + x);
+                    if (x < W && seg >= seg_lo && seg <= seg_hi) key = load_key(keys + (size_t)y * W + x);
                     if (key != 0u) {
                         const uint8_t* cs = colours + 3 * (size_t)(key & KEY_INDEX_MASK);
                         col = (uint32_t)cs[0] | ((uint32_t)cs[1] << 8) | ((uint32_t)cs[2] << 16);
                     }
+                    if (__ballot(key != 0u) != 0ull && x < W) keys[(size_t)y * W + x] = 0u;
                 }
                 const bool site = key != 0;
                 // the output image starts as the sparse image: data pixels carry their colour (they are also the vertex
@@ -745,9 +816,12 @@ __global__ __launch_bounds__(256) void halluc_apply_kernel(const uint8_t* __rest
 // interp_dense_grid_from_sparse (:21-54): sites given as pixel coordinates + colours -> key image (last index wins).
 __global__ __launch_bounds__(256) void keys_from_pixels_kernel(const int32_t* __restrict__ xy, const uint8_t* __restrict__ rgb, int n,
                                                                int W, int H, uint32_t* __restrict__ kimg,
-                                                               const uint8_t** __restrict__ colour_src) {
+                                                               const uint8_t** __restrict__ colour_src, int32_t* __restrict__ bbox) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) colour_src[0] = rgb;
+    if (i == 0) {
+        colour_src[0] = rgb;
+        bbox[0] = W; bbox[1] = H; bbox[2] = W; bbox[3] = H;
+    }
     if (i >= n) return;
     const int x = xy[2 * i], y = xy[2 * i + 1];
     if (x < 0 || x >= W || y < 0 || y >= H) return;
@@ -805,16 +879,25 @@ extern "C" {
 struct Workspace {
     unsigned long long* triq;
     const uint8_t** colour_src;
+    int32_t* bbox;      // [n][4], see bev_scatter_kernel
     uint32_t* keys;
     uint32_t* sitelist;
     uint32_t* hardlist;
 };
 
-static Workspace carve_workspace(void* workspace, size_t n, size_t npx) {
+static size_t workspace_per_render(size_t npx) {
+    return npx * (sizeof(unsigned long long) + 3 * sizeof(uint32_t)) + sizeof(void*) + 4 * sizeof(int32_t);
+}
+
+// The layout is a function of the buffer's CAPACITY (the renders its size holds), not of the launch's render count: the
+// key images must stay where salve_bev_workspace_init zeroed them when launches of different sizes share the buffer.
+static Workspace carve_workspace(void* workspace, size_t workspace_bytes, size_t npx) {
+    const size_t n = (workspace_bytes - 256) / workspace_per_render(npx);
     Workspace w;
     w.triq = reinterpret_cast<unsigned long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     w.colour_src = reinterpret_cast<const uint8_t**>(w.triq + n * npx);
-    w.keys = reinterpret_cast<uint32_t*>(w.colour_src + n);
+    w.bbox = reinterpret_cast<int32_t*>(w.colour_src + n);
+    w.keys = reinterpret_cast<uint32_t*>(w.bbox + 4 * n);
     w.sitelist = w.keys + n * npx;
     w.hardlist = w.sitelist + n * npx;
     return w;
@@ -824,7 +907,20 @@ size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n) {
     DevCfg d;
     if (n <= 0 || !make_devcfg(cfg, &d)) return 0;
     const size_t npx = (size_t)d.H * d.W;
-    return (size_t)n * (npx * (sizeof(unsigned long long) + 3 * sizeof(uint32_t)) + sizeof(void*)) + 256;
+    return (size_t)n * workspace_per_render(npx) + 256;
+}
+
+int salve_bev_workspace_init(const salve_bev_config_t* cfg, int32_t n, void* workspace, size_t workspace_bytes, void* stream) {
+    DevCfg d;
+    if (!make_devcfg(cfg, &d)) return SALVE_ERR_BAD_ARG;
+    if (n <= 0 || !workspace) { salve_fail("salve_bev_workspace_init: null pointer or bad count"); return SALVE_ERR_BAD_ARG; }
+    if (workspace_bytes < salve_bev_workspace_bytes(cfg, n)) { salve_fail("workspace too small"); return SALVE_ERR_WORKSPACE; }
+    const size_t npx = (size_t)d.H * d.W;
+    const Workspace ws = carve_workspace(workspace, workspace_bytes, npx);
+    const size_t cap = (workspace_bytes - 256) / workspace_per_render(npx);
+    // the key images of the whole capacity: zero once; from then on every densify launch leaves the images it read zeroed again
+    SALVE_HIP_CHECK(hipMemsetAsync(ws.keys, 0, cap * npx * sizeof(uint32_t), (hipStream_t)stream));
+    return SALVE_OK;
 }
 
 static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* pano_rgb, const uint16_t* pano_depth,
@@ -847,10 +943,11 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
     if (lds > 160 * 1024) { salve_fail("bev image does not fit the 160 KB LDS"); return SALVE_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     const size_t npx = (size_t)d.H * d.W;
-    const Workspace ws = carve_workspace(workspace, (size_t)n, npx);
+    const Workspace ws = carve_workspace(workspace, workspace_bytes, npx);
 
     if (scatter) {
-        SALVE_HIP_CHECK(hipMemsetAsync(ws.keys, 0, (size_t)n * npx * sizeof(uint32_t), s));
+        // (no clear of the key images: salve_bev_workspace_init zeroed them and every densify re-zeroes what it read)
+        SALVE_HIP_CHECK(hipMemsetAsync(ws.bbox, 0, (size_t)n * 4 * sizeof(int32_t), s));
         const int pts_per_block = SCATTER_THREADS * PTS_PER_THREAD;
         dim3 g1((d.npts + pts_per_block - 1) / pts_per_block, n);
         if (in_window) SALVE_HIP_CHECK(hipMemsetAsync(in_window, 0, (size_t)n * sizeof(int32_t), s));
@@ -861,7 +958,7 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         // then takes part in the atomic maximum: the result is the maximum over all contenders.
         for (int pass = 0; pass < 2; pass++) {
             hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, ws.keys,
-                               ws.colour_src, dbg_img_xy, in_window, pass);
+                               ws.colour_src, dbg_img_xy, in_window, ws.bbox, pass);
             SALVE_HIP_CHECK(hipGetLastError());
         }
     }
@@ -882,15 +979,16 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
                 attr_lds[slot] = lds;
             }
         }
-        hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, d, ws.keys, ws.colour_src, out_bev, ws.sitelist,
-                           ws.hardlist, ws.triq, dbg_mask, dbg_stats, (d.dbg_flags & 16) ? dbg_img_xy : nullptr, status);
-        SALVE_HIP_CHECK(hipGetLastError());
-        if (dbg_keys) {
+        if (dbg_keys) {   // before the densify kernel, which zeroes the key cells it reads
             const size_t total = (size_t)n * npx;
             hipLaunchKernelGGL(keys_export_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws.keys, ws.colour_src, npx, total,
                                reinterpret_cast<unsigned long long*>(dbg_keys));
             SALVE_HIP_CHECK(hipGetLastError());
         }
+        const DensifyCfg dc = {d.H, d.W, d.wpr, d.mask_half, d.out_flags, d.dbg_flags};
+        hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, dc, ws.keys, ws.bbox, ws.colour_src, out_bev, ws.sitelist,
+                           ws.hardlist, ws.triq, dbg_mask, dbg_stats, (d.dbg_flags & 16) ? dbg_img_xy : nullptr, status);
+        SALVE_HIP_CHECK(hipGetLastError());
     }
     return SALVE_OK;
 }
@@ -928,12 +1026,13 @@ int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, c
     if ((long long)n_points >= (1ll << 21)) { salve_fail("at most 2^21 - 1 points"); return SALVE_ERR_UNSUPPORTED; }
     if (workspace_bytes < salve_bev_workspace_bytes(cfg, 1)) { salve_fail("workspace too small"); return SALVE_ERR_WORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
-    const Workspace ws = carve_workspace(workspace, 1, (size_t)d.H * d.W);
+    const Workspace ws = carve_workspace(workspace, workspace_bytes, (size_t)d.H * d.W);
     SALVE_HIP_CHECK(hipMemsetAsync(ws.keys, 0, (size_t)d.H * d.W * sizeof(uint32_t), s));
+    SALVE_HIP_CHECK(hipMemsetAsync(ws.bbox, 0, 4 * sizeof(int32_t), s));
     SALVE_HIP_CHECK(hipMemsetAsync(n_in_window, 0, sizeof(int32_t), s));
     if (n_points > 0) {
         hipLaunchKernelGGL(bev_scatter_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, d, xyz, rgb, n_points, ws.keys,
-                           ws.colour_src, n_in_window);
+                           ws.colour_src, n_in_window, ws.bbox);
         SALVE_HIP_CHECK(hipGetLastError());
     }
     return SALVE_OK;
@@ -978,11 +1077,12 @@ int salve_bev_keys_from_pixels(const salve_bev_config_t* cfg, const int32_t* xy,
     if ((long long)n_points >= (1ll << 21)) { salve_fail("at most 2^21 - 1 points"); return SALVE_ERR_UNSUPPORTED; }
     if (workspace_bytes < salve_bev_workspace_bytes(cfg, 1)) { salve_fail("workspace too small"); return SALVE_ERR_WORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
-    const Workspace ws = carve_workspace(workspace, 1, (size_t)d.H * d.W);
+    const Workspace ws = carve_workspace(workspace, workspace_bytes, (size_t)d.H * d.W);
     SALVE_HIP_CHECK(hipMemsetAsync(ws.keys, 0, (size_t)d.H * d.W * sizeof(uint32_t), s));
+    SALVE_HIP_CHECK(hipMemsetAsync(ws.bbox, 0, 4 * sizeof(int32_t), s));
     if (n_points > 0) {
         hipLaunchKernelGGL(keys_from_pixels_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, xy, rgb, n_points, d.W, d.H, ws.keys,
-                           ws.colour_src);
+                           ws.colour_src, ws.bbox);
         SALVE_HIP_CHECK(hipGetLastError());
     }
     return SALVE_OK;

@@ -126,6 +126,10 @@ class BevRasteriser:
         ws = self._ws_slots.get(self.ws_slot)
         if ws is None or ws.numel() < need:
             ws = self._ws_slots[self.ws_slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            # key images zeroed once per buffer: the launches keep them clean (salve_hip.h: salve_bev_workspace_init)
+            with torch.cuda.device(self.device):
+                st = self.lib.salve_bev_workspace_init(ctypes.byref(self.cfg), n, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+            _lib.check(st, "salve_bev_workspace_init")
         return ws
 
     def upload_panos(self, rgb: np.ndarray, depth: np.ndarray) -> Tuple[torch.Tensor, torch.Tensor]:
