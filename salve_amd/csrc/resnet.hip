@@ -253,6 +253,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
 }
 
 #include "conv_wide.h"
+#include "stem_pool.h"
 
 // 3x3 / stride 2 / pad 1 max-pool on NHWC fp16, 8 channels (16 bytes) per thread.
 __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B,
@@ -668,6 +669,7 @@ struct ResnetHandle {
     int num_layers = 0, in_channels = 0, ncls = 0;
     std::vector<int> fused;  // per op: 1 = this op and the next two form a bottleneck block run by bottleneck_kernel
     std::vector<int> wide;   // per op: 0 = conv_igemm_kernel, else a conv_wide_kernel configuration (WIDE_*)
+    std::vector<int> stem;   // per op: 1 = this 7x7 / 2 convolution and the max-pool behind it run as stem_pool_kernel
 };
 
 // Alternative convolution kernels (conv_wide.h), selected with SALVE_CONV_WIDE=d|e|f when a handle is created.  They are
@@ -742,6 +744,25 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
         const char* e = getenv("SALVE_CONV_WIDE");   // unset: off; d, e, f: that alternative kernel wherever the shape allows it
         const int mode = !e ? WIDE_OFF : (e[0] == 'd' ? WIDE_256_K64_S2 : (e[0] == 'e' ? WIDE_128_K64_S1 : (e[0] == 'f' ? WIDE_PC_128 : WIDE_OFF)));
         for (size_t i = 0; i < h->ops.size(); i++) h->wide[i] = choose_wide(h->ops[i], mode);
+    }
+    h->stem.assign(h->ops.size(), 0);
+    {
+        const char* e = getenv("SALVE_STEM_FUSE");   // "0": keep the implicit-GEMM stem and the separate max-pool
+        for (size_t i = 0; (!e || atoi(e) != 0) && i + 1 < h->ops.size(); i++) {
+            const salve_resnet_op_t &a = h->ops[i], &b = h->ops[i + 1];
+            if (a.op != SALVE_OP_CONV || b.op != SALVE_OP_MAXPOOL) continue;
+            const bool shape = a.KH == 7 && a.KW == 8 && a.stride == 2 && a.pad == 3 && a.Cin == 8 && a.Cout == 64 && a.relu &&
+                               a.res_buf == SALVE_NO_BUF && a.in2_buf == SALVE_NO_BUF && b.in_buf == a.out_buf && b.Cin == 64 &&
+                               a.Hi % 4 == 0 && a.Wi % 4 == 0 && a.Wi <= STEM_MAX_W && (a.Wi / 2) % 16 == 0 && (a.Hi / 4) % STEM_R == 0 &&
+                               a.Ho == a.Hi / 2 && a.Wo == a.Wi / 2 && b.Ho == a.Hi / 4 && b.Wo == a.Wi / 4;
+            bool dead = shape;   // nobody else may read the un-pooled convolution output
+            for (size_t k = i + 2; dead && k < h->ops.size(); k++) {
+                const salve_resnet_op_t& o = h->ops[k];
+                if (o.in_buf == a.out_buf || (o.op == SALVE_OP_CONV && (o.res_buf == a.out_buf || o.in2_buf == a.out_buf))) dead = false;
+                if (o.out_buf == a.out_buf) break;
+            }
+            if (dead) h->stem[i] = 1;
+        }
     }
     h->fused.assign(h->ops.size(), 0);
     {
@@ -824,6 +845,22 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
     auto buf = [&](int i) -> uint16_t* { return i < 0 ? const_cast<uint16_t*>(reinterpret_cast<const uint16_t*>(input)) : base + (size_t)i * buf_elems; };
     for (size_t oi = 0; oi < h->ops.size(); oi++) {
         const salve_resnet_op_t& o = h->ops[oi];
+        if (o.op == SALVE_OP_CONV && h->stem[oi]) {
+            const salve_resnet_op_t& pool = h->ops[oi + 1];
+            StemArgs a;
+            a.x = buf(o.in_buf);
+            a.w = h->d_weights + o.w_off;
+            a.bias = h->d_params + o.b_off;
+            a.y = buf(pool.out_buf);
+            a.zeros = h->d_zeros;
+            a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status;
+            const long long grid = (long long)batch * ((o.Hi / 4) / STEM_R);
+            if (grid > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
+            hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)grid), dim3(STEM_THREADS), 0, s, a);
+            SALVE_HIP_CHECK(hipGetLastError());
+            oi += 1;
+            continue;
+        }
         if (o.op == SALVE_OP_CONV && h->fused[oi]) {
             const salve_resnet_op_t &ob = h->ops[oi + 1], &oc = h->ops[oi + 2];
             BottleneckArgs a;

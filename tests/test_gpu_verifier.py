@@ -221,6 +221,26 @@ def test_fused_bottleneck_is_bit_identical_to_three_kernels(monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool(monkeypatch):
+    """stem_pool_kernel (7x7 / 2 convolution + BatchNorm + ReLU + 3x3 / 2 max-pool in one launch, input patch in LDS) rounds
+    every convolution output to fp16 before the max, exactly as the two-kernel path stores it, and accumulates in the same k
+    order: the logits must agree bit for bit -- image borders (zero padding, pooling windows cut by the edge) included."""
+    torch.manual_seed(8)
+    model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"]))
+    randomise_bn(model, seed=8)
+    model.eval()
+    x = torch.randn(3, 224, 224, 8).to(torch.float16).to(DEV)
+    x[..., 6:] = 0
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SALVE_STEM_FUSE", fuse)   # read when the handle is created
+        eng = hip_resnet.HipResNet(model.state_dict(), 18, torch.device(DEV))
+        outs.append(eng.forward_nhwc(x).clone())
+        torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("cfg", ["d", "e", "f"])
 def test_alternative_convolution_kernels_are_bit_identical(monkeypatch, cfg):
     """SALVE_CONV_WIDE = d | e | f routes the convolutions through the wide-tile / split-role kernels of conv_wide.h where the
