@@ -163,6 +163,23 @@ int salve_bev_keys_from_pixels(const salve_bev_config_t* cfg, const int32_t* xy,
 int salve_resize_rgb_u8(const uint8_t* src, int32_t n, int32_t src_h, int32_t src_w, uint8_t* dst, int32_t dst_h, int32_t dst_w,
                         const int32_t* coef_y, const int32_t* coef_x, void* stream);
 
+/* Rasterised-LAYOUT modality: n images of a filled room polygon (white) with thick anti-aliased W/D/O segments over it, flipped
+ * vertically -- salve/utils/bev_rendering_utils.py:104-156 (rasterize_single_layout; cv2.fillPoly :159-179, cv2.line LINE_AA
+ * :210-251).  The host has already applied the pose, the x 1.5 factor, bevimg_Sim2_world and np.round (:187-188, :214-215):
+ *   layouts  device salve_layout_t [n]
+ *   poly_xy  device int32 [*, 2]: polygon vertices (x, y) in pixels (closing vertex optional)
+ *   segs     device int32 [*, 8]: x1, y1, x2, y2, colour 0x00BBGGRR, thickness in pixels, 0, 0
+ *   out      device uint32 [n, img_h, img_w], 0x00BBGGRR (the layout of salve_bev_render_batch's out_bev: salve_bev_tiles and
+ *            salve_bev_export_u8 take it as is)
+ * OpenCV's own pixel arithmetic is not installed here and not pinned by the reference's tests: the integer rules implemented
+ * are stated in oracle/layout_oracle.py ("parity unpinned"). */
+typedef struct {
+    int32_t n_poly, poly_off; /* vertex count and first vertex of this image's polygon in poly_xy */
+    int32_t n_seg, seg_off;   /* segment count and first segment in segs */
+} salve_layout_t;
+int salve_layout_rasterise(const salve_layout_t* layouts, int32_t n, const int32_t* poly_xy, const int32_t* segs, int32_t img_h,
+                           int32_t img_w, uint32_t* out, void* stream);
+
 /* BEV uint32 -> uint8 [n, bev_h, bev_w, 3], the array render_bev_image returns (bev_rendering_utils.py:328). */
 int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream);
 

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = (
     "salve_remove_hallucinated",
     "salve_bev_keys_from_pixels",
     "salve_bev_export_u8",
+    "salve_layout_rasterise",
     "salve_bev_tiles",
     "salve_resize_rgb_u8",
     "salve_resnet_create",
@@ -67,6 +68,7 @@ HYP_DTYPE = np.dtype(
      ("reserved", "<i4")]
 )
 TILE_JOB_DTYPE = np.dtype([("bev_offset", "<i8"), ("slot", "<i4"), ("chan", "<i4")])
+LAYOUT_DTYPE = np.dtype([("n_poly", "<i4"), ("poly_off", "<i4"), ("n_seg", "<i4"), ("seg_off", "<i4")])
 assert HYP_DTYPE.itemsize == 40 and TILE_JOB_DTYPE.itemsize == 16
 
 _lib = None
@@ -108,6 +110,8 @@ def load() -> ctypes.CDLL:
     lib.salve_remove_hallucinated.restype = ctypes.c_int
     lib.salve_bev_keys_from_pixels.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, sz, vp]
     lib.salve_bev_keys_from_pixels.restype = ctypes.c_int
+    lib.salve_layout_rasterise.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp]
+    lib.salve_layout_rasterise.restype = ctypes.c_int
     lib.salve_bev_export_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.salve_bev_export_u8.restype = ctypes.c_int
     lib.salve_bev_tiles.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]

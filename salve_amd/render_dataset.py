@@ -36,23 +36,29 @@ def available_floors(hypotheses_save_root: str, building_id: str) -> List[str]:
 
 def render_building_floor_pairs(depth_save_root: str, bev_save_root: str, hypotheses_save_root: str, raw_dataset_dir: str,
                                 building_id: str, floor_id: str, layout_save_root: Optional[str], render_modalities: List[str],
-                                multiprocess_building_panos: bool = False, num_processes: int = 1, device=None, batch: int = 256) -> int:
+                                multiprocess_building_panos: bool = False, num_processes: int = 1, device=None, batch: int = 256,
+                                floor_pose_graph=None) -> int:
     """All floor + ceiling texture maps of one floor (scripts/render_dataset_bev.py:34-117).  `multiprocess_building_panos`
     and `num_processes` are accepted for signature compatibility; the parallelism is the GPU's.  Returns the number of
-    JPEG files written."""
-    if "layout" in render_modalities:
-        raise NotImplementedError("the rasterised-layout modality is outside the accelerated hot path")
-    if "rgb_texture" not in render_modalities:
-        return 0
+    JPEG files written.
+    The "layout" modality needs the floor's pose graph with room layouts and W/D/O objects (the reference loads it with
+    hnet_prediction_loader, :61-75, which is outside this path): pass it as `floor_pose_graph`."""
+    if "layout" in render_modalities and floor_pose_graph is None:
+        raise NotImplementedError("the layout modality needs `floor_pose_graph` (loading inferred layouts is outside this path)")
     hyps = ingest.load_floor_hypotheses(hypotheses_save_root, building_id, floor_id)
     if len(hyps) == 0:
         return 0
     img_fpaths = ingest.floor_pano_fpaths(raw_dataset_dir, building_id)
+    written = 0
+    if "layout" in render_modalities:
+        written += _render_floor_layouts(hyps, img_fpaths, layout_save_root, floor_pose_graph, device)
+    if "rgb_texture" not in render_modalities:
+        return written
     names = {s: hyps.tile_paths(bev_save_root, img_fpaths, s) for s in SURFACE_TYPES}  # (tile of i1, tile of i2)
     todo = [(j, s) for j in range(len(hyps)) for s in SURFACE_TYPES
             if not (Path(names[s][j][0]).exists() and Path(names[s][j][1]).exists())]   # both exist: skip (idempotent restart)
     if not todo:
-        return 0
+        return written
     dev = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
     needed = sorted({int(p) for j, _ in todo for p in (hyps.i1[j], hyps.i2[j])})
     store = ingest.PanoStore(dev).load(img_fpaths, depth_save_root, building_id, needed)
@@ -79,7 +85,6 @@ def render_building_floor_pairs(depth_save_root: str, bev_save_root: str, hypoth
     ident_img, ident_cnt = render([(store.index[p], s, eye, zero, 0) for p, s in ident_keys])
     ident = {k: (ident_img[i], int(ident_cnt[i])) for i, k in enumerate(ident_keys)}
     posed_img, posed_cnt = render([(store.index[int(hyps.i1[j])], s, hyps.R[j], hyps.t[j], 1) for j, s in todo])
-    written = 0
     for k, (j, s) in enumerate(todo):
         img2, cnt2 = ident[(int(hyps.i2[j]), s)]
         if int(posed_cnt[k]) == 0 or cnt2 == 0:
@@ -88,6 +93,37 @@ def render_building_floor_pairs(depth_save_root: str, bev_save_root: str, hypoth
         os.makedirs(os.path.dirname(fp1), exist_ok=True)
         image_io.write_jpeg(fp1, posed_img[k])
         image_io.write_jpeg(fp2, img2)
+        written += 2
+    return written
+
+
+def _render_floor_layouts(hyps, img_fpaths: Dict[int, str], layout_save_root: str, floor_pose_graph, device) -> int:
+    """Layout tiles of every hypothesis of a floor in one launch (bev_rendering_utils.py:632-663: `floor` names only, skip if
+    both files exist).  The layout of pano i2 does not depend on the hypothesis: rendered once per panorama."""
+    from salve_amd import layout
+    from salve_amd.common.sim2 import Sim2
+    from salve_amd.rasteriser import BevRasteriser
+
+    paths = hyps.tile_paths(layout_save_root, img_fpaths, "floor")
+    todo = [j for j in range(len(hyps)) if not (Path(paths[j][0]).exists() and Path(paths[j][1]).exists())]
+    if not todo:
+        return 0
+    dev = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+    specs, ident_of = [], {}
+    for j in todo:
+        S = Sim2(hyps.R[j], hyps.t[j], float(hyps.s[j]))
+        s1, s2 = layout.layout_pair_specs(S, floor_pose_graph, int(hyps.i1[j]), int(hyps.i2[j]))
+        specs.append(s1)
+        ident_of.setdefault(int(hyps.i2[j]), s2)
+    ident_ids = sorted(ident_of)
+    imgs = layout.rasterise_layouts(specs + [ident_of[p] for p in ident_ids], dev)
+    u8 = BevRasteriser(dev).export_u8(imgs).cpu().numpy()
+    written = 0
+    for k, j in enumerate(todo):
+        fp1, fp2 = paths[j]
+        os.makedirs(os.path.dirname(fp1), exist_ok=True)
+        image_io.write_jpeg(fp1, u8[k])
+        image_io.write_jpeg(fp2, u8[len(todo) + ident_ids.index(int(hyps.i2[j]))])
         written += 2
     return written
 

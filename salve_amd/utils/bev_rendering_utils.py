@@ -2,8 +2,8 @@
 
 Mirror of salve/utils/bev_rendering_utils.py (the texture-map half: :38-45, :254-328, :347-630).  Signatures,
 return conventions (None / (None, None)), exceptions and output file names follow the reference so that
-scripts/render_dataset_bev.py can call these functions unchanged.  The rasterised-LAYOUT modality (:48-251) is a
-baseline ablation outside this hot path and raises NotImplementedError.
+scripts/render_dataset_bev.py can call these functions unchanged.  The rasterised-LAYOUT modality (:48-251) runs on the
+GPU too (salve_amd/layout.py, csrc/layout.hip); OpenCV's own anti-aliasing arithmetic is unpinned (oracle/layout_oracle.py).
 
 What runs where: file decoding (PIL) and the 2x pano down-scale are host-side ingest; back-projection, pose,
 pixel indices, z-order, densification, mask and flip run on the GPU (salve_amd/csrc/bev_render.hip).  There is
@@ -218,5 +218,39 @@ def generate_texture_maps_for_pair(
         image_io.write_jpeg(bev_fpath1, bev_img1)
         image_io.write_jpeg(bev_fpath2, bev_img2)
 
-    if "layout" in render_modalities:
-        raise NotImplementedError("the rasterised-layout modality is outside the accelerated hot path")
+    if "layout" not in render_modalities:
+        return
+    # Rasterised layout (:632-663): only for `floor` (the ceiling rendering would be identical), same file names under
+    # layout_save_root, same skip-if-both-exist rule.
+    if surface_type != "floor":
+        return
+    building_layout_save_dir = f"{layout_save_root}/{label_type}/{building_id}"
+    os.makedirs(building_layout_save_dir, exist_ok=True)
+    layout_fpath1 = f"{building_layout_save_dir}/{Path(bev_fpath1).name}"
+    layout_fpath2 = f"{building_layout_save_dir}/{Path(bev_fpath2).name}"
+    if Path(layout_fpath1).exists() and Path(layout_fpath2).exists():
+        return
+    layoutimg1, layoutimg2 = rasterize_room_layout_pair(i2Ti1, floor_pose_graph, building_id, floor_id, i1, i2)
+    image_io.write_jpeg(layout_fpath1, layoutimg1)
+    image_io.write_jpeg(layout_fpath2, layoutimg2)
+
+
+def rasterize_single_layout(bev_params: BEVParams, room_vertices: np.ndarray, wdo_objs, render_mask: bool = True) -> np.ndarray:
+    """Room layout in white, windows / doors / openings as thick coloured segments, flipped vertically (reference :104-156).
+    `wdo_objs`: objects with `.type` and `.vertices_local_2d`."""
+    from salve_amd import layout
+
+    spec = (np.asarray(room_vertices, dtype=np.float64), [(w.type, np.asarray(w.vertices_local_2d, dtype=np.float64)) for w in wdo_objs])
+    img = layout.rasterise_layouts([spec], _device(), bev_params, render_mask=render_mask)
+    return _rasteriser(bev_params).export_u8(img).cpu().numpy()[0]
+
+
+def rasterize_room_layout_pair(i2Ti1: Sim2, floor_pose_graph, building_id: str, floor_id: str, i1: int, i2: int) -> Tuple[np.ndarray, np.ndarray]:
+    """BEV rasterisation of the layouts of panoramas i1 (moved into i2's frame by i2Ti1) and i2 (reference :48-101)."""
+    from salve_amd import layout
+
+    bp = BEVParams()
+    s1, s2 = layout.layout_pair_specs(i2Ti1, floor_pose_graph, i1, i2)
+    img = layout.rasterise_layouts([s1, s2], _device(), bp)
+    out = _rasteriser(bp).export_u8(img).cpu().numpy()
+    return out[0], out[1]

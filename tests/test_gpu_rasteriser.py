@@ -177,3 +177,29 @@ def test_cluttered_scene_renders_match_oracle():
                 assert np.array_equal(got[k], res["bev"]), f"cluttered scene, render {k} ({surface})"
     print(f"hard-site share: box room {shares['box']:.4f}, cluttered room {shares['cluttered']:.4f}")
     assert shares["cluttered"] > shares["box"]
+
+
+def test_render_is_exact_next_to_an_mfma_only_kernel(setup):
+    """packed fp32 VALU instructions (which -O3's SLP vectoriser once put into the exact float32
+    predicates of the star walks) returned timing-dependent wrong results while a wave of ANOTHER kernel issued MFMAs on the
+    same CU.  The library is built with -fno-slp-vectorize; this regression test renders -- general star walk included --
+    while the MFMA-only synthetic kernel (salve_amd/csrc/salve_debug.h: salve_debug_burn, mode 0) occupies the matrix pipes
+    from a second stream, and requires the images of a quiet render, bit for bit."""
+    import ctypes
+
+    ras, panos, d_rgb, d_depth, hyp = setup
+    n = 16
+    h = pack_hypotheses(hyp.i1[:n], np.arange(n) % 2, hyp.R[:n], hyp.t[:n], np.ones(n))
+    hd = ras.upload_hypotheses(h)
+    quiet, dbg = ras.render(d_rgb, d_depth, hd, n, debug=True)
+    torch.cuda.synchronize()
+    quiet = quiet.clone()
+    assert int(dbg.stats[:, 6].sum()) > 0          # hard sites exist: the general walk runs
+    sink = torch.zeros(1, dtype=torch.float32, device=ras.device)
+    side = torch.cuda.Stream(ras.device)
+    for _ in range(3):
+        st = ras.lib.salve_debug_burn(4096, 4000, 0, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+        assert st == 0
+        loud, _ = ras.render(d_rgb, d_depth, hd, n)
+        torch.cuda.synchronize()
+        assert torch.equal(loud, quiet)
