@@ -137,9 +137,12 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hyps", type=int, default=4096, help="hypotheses per GPU")
     ap.add_argument("--panos", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=1024, help="hypotheses per render / verify launch")
-    ap.add_argument("--no-overlap", action="store_true", help="render and verify on one HIP stream")
-    ap.add_argument("--streams", type=int, default=3, help="2: rasteriser | verifier; 3: scatter | densify | verifier")
+    ap.add_argument("--chunk", type=int, default=4096, help="hypotheses per render / verify launch (the whole shard: launches of 4096 renders /\n"
+                    "samples run 10 % faster per unit than launches of 1024; the rasteriser of pass k + 1 runs under the verifier of pass k)")
+    ap.add_argument("--no-overlap", action="store_true", help="same as --streams 1")
+    ap.add_argument("--streams", type=int, default=1, help="1: one HIP stream (default: with whole-shard launches the overlapped schedules gain\n"
+                    "1 % -- the kernels then share the CUs and each runs longer -- and blur the per-kernel times the rooflines are computed from);\n"
+                    "2: rasteriser | verifier; 3: scatter | densify | verifier, the rasteriser of pass k + 1 under the verifier of pass k")
     ap.add_argument("--layers", type=int, default=50)
     ap.add_argument("--scene", default="box", help="synthetic scene: box (SURVEY 8d) | cluttered (occluding boxes + door opening)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,7 +169,7 @@ def main() -> None:
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(args.layers, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
     synthetic.trained_looking_batchnorm(model)  # random-init weights of the named architecture; seeded trained-looking statistics
-    pipe = RenderVerifyPipeline(model, dev, pano_hw=(PANO_H, PANO_W), chunk=args.chunk, overlap=not args.no_overlap, streams=args.streams)
+    pipe = RenderVerifyPipeline(model, dev, pano_hw=(PANO_H, PANO_W), chunk=args.chunk, overlap=(args.streams > 1 and not args.no_overlap), streams=args.streams)
     panos = [synthetic.make_pano(i, PANO_H, PANO_W, scene=args.scene) for i in range(args.panos)]
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     # weak scaling: every rank scores its own block of `hyps` hypotheses out of a table of world * hyps
@@ -216,7 +219,8 @@ def main() -> None:
             "config": {"workload": f"{args.hyps} hypotheses/GPU over {args.panos} synthetic 1024x512 panoramas ({args.scene} scene), floor surface, "
                                    f"HIP BEV rasteriser + ResNet-{args.layers} (6-ch early fusion) fp16 MFMA verifier",
                        "hypotheses_per_gpu": args.hyps, "panos": args.panos, "renders_per_hypothesis": 1,
-                       "cached_identity_renders": args.panos, "chunk": args.chunk, "parallelism": f"hypothesis-shard x{world}"},
+                       "cached_identity_renders": args.panos, "chunk": args.chunk, "hip_streams": 1 if args.no_overlap else args.streams,
+                       "parallelism": f"hypothesis-shard x{world}"},
             # the rasteriser as a whole (key-image clear + two scatter passes + densify): SURVEY 8d's 2.555 MB per render x the
             # renders of one launch / the summed average durations of those launches (HIP events on the launching streams)
             "roofline": {"kernel": "rasteriser: key-image clear + bev_scatter_kernel x2 + bev_densify_kernel", "bound": "hbm",

@@ -72,6 +72,12 @@ class RenderVerifyPipeline:
         self.scatter_stream = torch.cuda.Stream(self.device) if (overlap and streams >= 3) else None
         self.pano_rgb = self.pano_depth = self.ref_bev = self.ref_in_window = None
         self.n_panos = 0
+        # event bookkeeping of score(): running chunk number, last densify per workspace slot, last verifier per buffer set
+        self._seq = 0
+        self._densified = [None, None]
+        self._consumed = [None] * self.nbuf
+        self._panos_ready = None
+        self.last_chunk_buffer = {}   # chunk index of the last score() call -> buffer set (self.bevs / self.tile_bufs) it used
 
     # ------------------------------------------------------------------ panoramas
     def load_panos(self, rgb: np.ndarray, depth: np.ndarray) -> None:
@@ -98,6 +104,10 @@ class RenderVerifyPipeline:
                 n = min(256, P * S - lo)
                 self.ras.render_counted(self.pano_rgb, self.pano_depth, hd[lo * _lib.HYP_DTYPE.itemsize:], n, self.ref_bev[lo:lo + n],
                                         self.ref_in_window[lo:lo + n])
+        # render_counted used workspace slot 0 on the current stream: later launches on other streams wait for this event
+        self._panos_ready = torch.cuda.Event()
+        self._panos_ready.record(torch.cuda.current_stream(self.device))
+        self._densified[0] = self._panos_ready
 
     # ------------------------------------------------------------------ hypotheses
     def prepare(self, hyp: HypothesisTable):
@@ -122,14 +132,17 @@ class RenderVerifyPipeline:
             jobs2_chan.append(6 * si + 3 * (1 - swap))
         # job tables are stored hypothesis-major so that a chunk is a contiguous slice
         st = lambda parts: np.stack(parts, 1).reshape(-1)
-        return {
+        prepared = {
             "n": N,
             "i2": np.asarray(hyp.i2).astype(np.int64),
             "rows": self.ras.upload_hypotheses(rows),
             "jobs1": self.ras.upload_tile_jobs(st(jobs1_bev), st(jobs1_slot), st(jobs1_chan)),
             "jobs2": self.ras.upload_tile_jobs(st(jobs2_bev), st(jobs2_slot), st(jobs2_chan)),
             "in_window": torch.zeros(N * S, dtype=torch.int32, device=self.device),  # posed renders, filled by score()
+            "ready": torch.cuda.Event(),   # the tables are on the device: launches on other streams wait for it
         }
+        prepared["ready"].record(torch.cuda.current_stream(self.device))
+        return prepared
 
     @staticmethod
     def _timed(timers, units: int, tag: str):
@@ -178,58 +191,53 @@ class RenderVerifyPipeline:
             vtimers.append((e0, e1, n))
 
     def score(self, prepared, out: Optional[torch.Tensor] = None, timers=None, vtimers=None) -> torch.Tensor:
-        """Render + verify every hypothesis of a prepared shard.  Returns fp32 logits [N, num_classes].
-        `timers` / `vtimers` = lists: receive (start event, end event, units, "scatter" | "densify") for the rasteriser
-        launches / (start, end, units) for the verifier forward of every chunk (benchmark rooflines; the events are recorded
-        on the stream the kernels are launched on)."""
+        """Render + verify every hypothesis of a prepared shard.  Returns fp32 logits [N, num_classes] (complete once the
+        CURRENT stream has caught up).  `timers` / `vtimers` = lists: receive (start event, end event, units, "scatter" |
+        "densify") for the rasteriser launches / (start, end, units) for the verifier forward of every chunk (benchmark
+        rooflines; the events are recorded on the stream the kernels are launched on).
+
+        Streams: the verifier always runs on the current stream; with overlap the scatter and the densify + tile kernels run
+        on their own streams, ordered by events only -- a workspace slot is reused once the densify that read it is done, a
+        buffer set once the verifier that read it is done -- so the rasteriser of the NEXT chunk, or of the next call, runs
+        under the verifier of this one.  Nothing is joined at the end of a call: everything a caller can observe (the
+        logits, the in-window counts, the BEV buffers of this call) is complete when the current stream is."""
         N = prepared["n"]
         if out is None:
             out = torch.empty((N, self.engine.num_classes), dtype=torch.float32, device=self.device)
-        chunks = [(lo, min(self.chunk, N - lo)) for lo in range(0, N, self.chunk)]
-        if self.render_stream is None:
-            for lo, n in chunks:
-                self._scatter_chunk(prepared, lo, n, 0, timers)
-                self._densify_chunk(prepared, lo, n, 0, 0, timers)
-                self._verify_chunk(0, n, out[lo:lo + n], vtimers)
-            return out
         main = torch.cuda.current_stream(self.device)
-        self.render_stream.wait_stream(main)
-        consumed = [torch.cuda.Event() for _ in chunks]
-        densified = [torch.cuda.Event() for _ in chunks]
-        if self.scatter_stream is not None:
-            self.scatter_stream.wait_stream(main)
-            scattered = [torch.cuda.Event() for _ in chunks]
-            for i, (lo, n) in enumerate(chunks):
-                with torch.cuda.stream(self.scatter_stream):
-                    if i >= 2:
-                        self.scatter_stream.wait_event(densified[i - 2])  # that densify is done with this workspace
-                    self._scatter_chunk(prepared, lo, n, i % 2, timers)
-                    scattered[i].record(self.scatter_stream)
-                with torch.cuda.stream(self.render_stream):
-                    self.render_stream.wait_event(scattered[i])
-                    if i >= self.nbuf:
-                        self.render_stream.wait_event(consumed[i - self.nbuf])  # the verifier is done with this buffer set
-                    self._densify_chunk(prepared, lo, n, i % self.nbuf, i % 2, timers)
-                    densified[i].record(self.render_stream)
-                main.wait_event(densified[i])
-                self._verify_chunk(i % self.nbuf, n, out[lo:lo + n], vtimers)
-                consumed[i].record(main)
-            self.render_stream.wait_stream(main)
-            self.scatter_stream.wait_stream(self.render_stream)
-            main.wait_stream(self.scatter_stream)
-            self.ras.ws_slot = 0
-            return out
-        for i, (lo, n) in enumerate(chunks):
-            with torch.cuda.stream(self.render_stream):
-                if i >= self.nbuf:
-                    self.render_stream.wait_event(consumed[i - self.nbuf])  # the verifier is done with this buffer set
-                self._scatter_chunk(prepared, lo, n, 0, timers)
-                self._densify_chunk(prepared, lo, n, i % self.nbuf, 0, timers)
-                densified[i].record(self.render_stream)
-            main.wait_event(densified[i])
-            self._verify_chunk(i % self.nbuf, n, out[lo:lo + n], vtimers)
-            consumed[i].record(main)
-        self.render_stream.wait_stream(main)
+        rs = self.render_stream or main
+        ss = self.scatter_stream or rs
+        n_slots = 2 if self.scatter_stream is not None else 1
+        self.last_chunk_buffer = {}
+        for ci, lo in enumerate(range(0, N, self.chunk)):
+            n = min(self.chunk, N - lo)
+            seq = self._seq
+            self._seq += 1
+            buf, slot = seq % self.nbuf, seq % n_slots
+            self.last_chunk_buffer[ci] = buf
+            with torch.cuda.stream(ss):
+                if ss is not main:
+                    ss.wait_event(prepared["ready"])
+                    ss.wait_event(self._panos_ready)
+                if self._densified[slot] is not None:
+                    ss.wait_event(self._densified[slot])      # the densify that read this workspace slot is done
+                self._scatter_chunk(prepared, lo, n, slot, timers)
+                scattered = torch.cuda.Event()
+                scattered.record(ss)
+            with torch.cuda.stream(rs):
+                if rs is not ss:
+                    rs.wait_event(scattered)
+                if self._consumed[buf] is not None:
+                    rs.wait_event(self._consumed[buf])        # the verifier that read this buffer set is done
+                self._densify_chunk(prepared, lo, n, buf, slot, timers)
+                self._densified[slot] = torch.cuda.Event()
+                self._densified[slot].record(rs)
+            if rs is not main:
+                main.wait_event(self._densified[slot])
+            self._verify_chunk(buf, n, out[lo:lo + n], vtimers)
+            self._consumed[buf] = torch.cuda.Event()
+            self._consumed[buf].record(main)
+        self.ras.ws_slot = 0
         return out
 
     def valid_mask(self, prepared) -> np.ndarray:

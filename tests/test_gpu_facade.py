@@ -127,7 +127,7 @@ def test_full_size_properties():
     assert torch.equal(a, pipe3.score(pipe3.prepare(table)))
     pipe.score(pipe.prepare(table.shard(0, 6)))  # the first 16 hypotheses: one chunk, lands in bev[0:16]
     torch.cuda.synchronize()
-    assert torch.equal(pipe.bev[0], pipe.ref_bev[int(table.i1[0])])
+    assert torch.equal(pipe.bevs[pipe.last_chunk_buffer[0]][0], pipe.ref_bev[int(table.i1[0])])
     # two ranks' shards reproduce the single-rank logits
     parts = [pipe.score(pipe.prepare(table.shard(r, 2))).clone() for r in range(2)]
     assert torch.equal(torch.cat(parts), a)

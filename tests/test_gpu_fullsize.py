@@ -52,10 +52,9 @@ def test_config2_config3_at_benchmark_size():
             torch.cuda.synchronize()
             pipe.check(f"full size, {streams} stream(s)")
             assert pipe.valid_mask(prepared).all()
-            if overlap:
-                bev_last = {2: pipe.bevs[0].clone(), 3: pipe.bevs[1].clone()}   # chunk 2 -> buffer 0, chunk 3 -> buffer 1
-            else:
-                bev_last = {3: pipe.bevs[0].clone()}
+            # the BEV images still resident after the pass: those of the last chunk (one buffer set) or the last two
+            last = sorted(pipe.last_chunk_buffer)[-pipe.nbuf:]
+            bev_last = {ci: pipe.bevs[pipe.last_chunk_buffer[ci]].clone() for ci in last}
             results[streams] = (logits.clone(), bev_last, pipe)
         oracle = pending.get(timeout=900)
 

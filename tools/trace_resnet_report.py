@@ -3,9 +3,9 @@
 import csv, glob, sys
 d = sys.argv[1]
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "maxpool", "avgpool", "bottleneck"))]
+rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv_wide", "conv_pc", "stem_pool", "maxpool", "avgpool", "bottleneck"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-n_per = len(rows) // 3
+n_per = len(rows) // 3   # tools/trace_resnet.py runs three forwards; the last one is reported
 tot = 0
 for i, r in enumerate(rows[-n_per:]):
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
