@@ -16,25 +16,26 @@ def stats(d, title, tag):
         out.append(f"| {short(r['Name'])} | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
     return out, rows
 
-b3, b1, bc = line("bench.log"), line("bench_1s.log"), line("bench_cluttered.log")
-(PRO / "r02_bench_line.json").write_text(json.dumps(b3) + "\n")
-(PRO / "r02_bench_line_one_stream.json").write_text(json.dumps(b1) + "\n")
+b1, b3, bc = line("bench.log"), line("bench_3s.log"), line("bench_cluttered.log")   # default (one stream), --streams 3, cluttered scene
+(PRO / "r02_bench_line.json").write_text(json.dumps(b1) + "\n")
+(PRO / "r02_bench_line_three_streams.json").write_text(json.dumps(b3) + "\n")
 (PRO / "r02_bench_line_cluttered_scene.json").write_text(json.dumps(bc) + "\n")
-o, rows = stats("prof3", ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   (round 2, MI355X, 4096 hypotheses, chunk 1024)",
-                          "# the default three-stream run: scatter, densify and verifier kernels overlap, per-kernel durations include the slow-down from sharing the CUs",
-                          f"# bench line of the same build without the profiler: r02_bench_line.json ({b3['value'] / 1e3:.1f} k hypotheses/s)"], "")
-d = [r for r in rows if "bev_densify" in r["Name"]][0]
-s = [r for r in rows if "bev_scatter_kernel" in r["Name"]][0]
-o += ["", f"bev_densify_kernel: {d['Calls']} launches = 12 of 1024 renders + 1 of 64 (identity renders): about {(int(d['TotalDurationNs']) / 1e6 - 0.8) / 12:.2f} ms per 1024-render launch;",
-      f"bev_scatter_kernel: {s['Calls']} launches (two passes each): about {int(s['TotalDurationNs']) / 1e6 / 12.06:.2f} ms per 1024 renders; bench.py's live HIP events of its own run:",
-      f"roofline.scatter_ms = {b3['roofline']['scatter_ms']}, densify_ms = {b3['roofline']['densify_ms']}, roofline_verifier.launch_ms = {b3['roofline_verifier']['launch_ms']}."]
-(PRO / "r02_bench_kernel_stats.md").write_text("\n".join(o) + "\n")
-o1, rows1 = stats("prof1", ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap   (same build, ONE stream)",
-                            f"# per-kernel durations without the other streams' kernels on the CUs; {b1['value'] / 1e3:.1f} k hypotheses/s in this mode"], "_one_stream")
-ver = sum(int(r["TotalDurationNs"]) for r in rows1 if any(k in r["Name"] for k in ("conv_igemm", "bottleneck", "stem_pool", "maxpool", "avgpool"))) / 1e6 / 12
-o1 += ["", f"verifier kernels per 1024 samples: {ver:.2f} ms = {1024 * 8.41 / ver:.0f} TFLOP/s = {1024 * 8.41 / ver / 25:.1f} % of the 2.5 PFLOP/s dense fp16 peak;",
-       f"bench.py's live HIP events in one-stream mode: scatter {b1['roofline']['scatter_ms']} ms + densify {b1['roofline']['densify_ms']} ms + verifier {b1['roofline_verifier']['launch_ms']} ms per 1024."]
-(PRO / "r02_bench_kernel_stats_one_stream.md").write_text("\n".join(o1) + "\n")
+o1, rows1 = stats("prof1", ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   (round 2, MI355X: the benchmark's defaults,",
+                            "# 4096 hypotheses in ONE launch per stage, one HIP stream)",
+                            f"# bench line of the same build without the profiler: r02_bench_line.json ({b1['value'] / 1e3:.1f} k hypotheses/s)"], "")
+n_launch = 3  # warm-up + 2 steps
+d = [r for r in rows1 if "bev_densify" in r["Name"]][0]
+sc = [r for r in rows1 if "bev_scatter_kernel" in r["Name"]][0]
+ver = sum(int(r["TotalDurationNs"]) for r in rows1 if any(k in r["Name"] for k in ("conv_igemm", "bottleneck", "stem_pool", "maxpool", "avgpool"))) / 1e6 / n_launch
+o1 += ["", f"bev_densify_kernel: {d['Calls']} launches = {n_launch} of 4096 renders + 1 of 64 (identity renders): {(int(d['TotalDurationNs']) / 1e6 - 0.8) / n_launch:.2f} ms per 4096 renders;",
+       f"bev_scatter_kernel: {sc['Calls']} launches (two passes each): {int(sc['TotalDurationNs']) / 1e6 / (n_launch + 64 / 4096):.2f} ms per 4096 renders;",
+       f"verifier kernels: {ver:.2f} ms per 4096 samples = {4096 * 8.41 / ver:.0f} TFLOP/s = {4096 * 8.41 / ver / 25:.1f} % of the 2.5 PFLOP/s dense fp16 peak.",
+       f"bench.py's live HIP events of its own (un-profiled) run: scatter {b1['roofline']['scatter_ms']} ms, densify {b1['roofline']['densify_ms']} ms, verifier {b1['roofline_verifier']['launch_ms']} ms."]
+(PRO / "r02_bench_kernel_stats.md").write_text("\n".join(o1) + "\n")
+o, rows = stats("prof3", ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 3   (same build: scatter | densify | verifier",
+                          "# on three streams, the rasteriser of pass k + 1 under the verifier of pass k; per-kernel durations include the slow-down from sharing the CUs)",
+                          f"# bench line: r02_bench_line_three_streams.json ({b3['value'] / 1e3:.1f} k hypotheses/s)"], "_three_streams")
+(PRO / "r02_bench_kernel_stats_three_streams.md").write_text("\n".join(o) + "\n")
 
 # ---- verifier SQ counters + per-launch trace (tools/trace_resnet.py, batch 512, last of three forwards)
 def counters(d):
