@@ -203,3 +203,57 @@ def test_render_is_exact_next_to_an_mfma_only_kernel(setup):
         loud, _ = ras.render(d_rgb, d_depth, hd, n)
         torch.cuda.synchronize()
         assert torch.equal(loud, quiet)
+
+
+def test_gpu_output_against_the_reference_own_images():
+    """The three full-size golden cases (tests/golden/g4_render_full.npz: images the IMPORTED REFERENCE produced) rendered on
+    the GPU and compared with the reference's output directly, not through the oracle: everything outside co-circular
+    configurations agrees (Tier A / B), the Tier-C pixels -- where the reference's own value depends on Qhull's input
+    order -- stay within the ceilings of tests/test_oracle_structure.py (12 % of the covered pixels, mean 2.5 grey levels),
+    and the HIP verifier's logits on GPU tiles vs reference tiles differ by less than 1e-3."""
+    from pathlib import Path
+    from types import SimpleNamespace
+
+    from _helpers import randomise_bn
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "g4_render_full.npz")
+    dev = torch.device("cuda:0")
+    ras = BevRasteriser(dev)
+    hyp = synthetic.make_hypotheses(16, 1, seed=0)
+    panos = {i: synthetic.make_pano(i) for i in (0, 1)}
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    randomise_bn(model)
+    eng = model.compiled(dev)
+    for ci in range(3):
+        hi = int(g[f"c{ci}_hyp"][0])
+        surface = int(g[f"c{ci}_surface"][0])
+        pa, pb = (int(v) for v in g[f"c{ci}_panos"])
+        d_rgb, d_depth = ras.upload_panos(np.stack([panos[pa][0], panos[pb][0]]), np.stack([panos[pa][1], panos[pb][1]]))
+        h = pack_hypotheses([0, 1], [surface, surface], np.stack([hyp.R[hi], np.eye(2, dtype=np.float32)]),
+                            np.stack([hyp.t[hi], np.zeros(2, np.float32)]), [1, 0])
+        bev, dbg = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), 2, debug=True)
+        got = ras.export_u8(bev).cpu().numpy()
+        # the pixel indices are the reference's, bit for bit (row a4)
+        xy = dbg.img_xy[0].cpu().numpy()
+        assert np.array_equal(xy[xy[:, 0] >= 0], g[f"c{ci}_img_xy"])
+        for k, name in enumerate(("bev1", "bev2")):
+            ref = g[f"c{ci}_{name}"]
+            d = np.abs(got[k].astype(int) - ref.astype(int)).max(-1)
+            covered = got[k].any(-1) | ref.any(-1)
+            frac, mean = (d > 0).sum() / covered.sum(), d[covered].mean()
+            print(f"case {ci} {name}: GPU vs reference: {100 * frac:.1f} % of covered pixels differ, mean {mean:.2f} grey levels, max {d.max()}")
+            assert frac <= 0.12 and mean <= 2.5 and d.max() <= 128
+        # logits of the HIP verifier on the GPU's tiles and on the reference's images
+        jobs = ras.upload_tile_jobs([0, 1, 0, 1], [0, 0, 1, 1], [0, 3, 0, 3])
+        ref_bev = torch.from_numpy(np.stack([g[f"c{ci}_bev1"], g[f"c{ci}_bev2"]]).astype(np.int32)).to(dev)
+        ref_u32 = (ref_bev[..., 0] | (ref_bev[..., 1] << 8) | (ref_bev[..., 2] << 16)).contiguous()
+        both = torch.cat([bev, ref_u32], 0).contiguous()
+        jobs = ras.upload_tile_jobs([0, 1, 2, 3], [0, 0, 1, 1], [0, 3, 0, 3])
+        tiles = torch.zeros((2, 224, 224, eng.in_channels), dtype=torch.float16, device=dev)
+        ras.tiles(both, jobs, 4, tiles, _lib.TILE_F16_NHWC, eng.in_channels)
+        logits = eng.forward_nhwc(tiles).cpu()
+        dl = float((logits[0] - logits[1]).abs().max())
+        print(f"case {ci}: |dlogit| GPU tiles vs reference tiles {dl:.2e}")
+        assert dl <= 1e-3

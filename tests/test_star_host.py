@@ -2,6 +2,7 @@
 from the very same headers, against the independent CPU oracle (incremental insertion + flips)."""
 
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
@@ -17,7 +18,9 @@ ROOT = Path(__file__).resolve().parents[1]
 @pytest.fixture(scope="module")
 def lib(tmp_path_factory):
     so = tmp_path_factory.mktemp("star") / "star_host.so"
-    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", str(so), str(ROOT / "tests" / "host" / "star_host.cpp")], check=True)
+    # STAR_HOST_CXXFLAGS: extra flags, e.g. "-fsanitize=undefined -fno-sanitize-recover=all" (sanitizers run on the CPU build only)
+    extra = os.environ.get("STAR_HOST_CXXFLAGS", "").split()
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC"] + extra + ["-o", str(so), str(ROOT / "tests" / "host" / "star_host.cpp")], check=True)
     return ctypes.CDLL(str(so))
 
 
