@@ -96,7 +96,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
         n_tile = r >> 3;
         if (m_tile >= p.m_tiles) return;
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases need no per-load readfirstlane
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int row_base = tid >> 3;                           // 0..31, plus i * 32
@@ -104,7 +104,6 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
 
     // per-thread im2col rows (fixed for the whole K loop)
     int iy0[4], ix0[4];
-    long long boff[4];
     const uint16_t* rowp[4];  // POINTWISE: the input pixel's channels (or the zero page, with stride 0)
     const uint16_t* rowp2[4];
 #pragma unroll
@@ -119,14 +118,17 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
         if (POINTWISE) {
             rowp[i] = valid ? p.in + (long long)m * p.Cin + chunk * 8 : nullptr;
             iy0[i] = ix0[i] = 0;
-            boff[i] = 0;
         } else {
             const int mm = valid ? m : 0;
             const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
             iy0[i] = valid ? oy * p.stride - p.pad : -100000;  // rows beyond M read zeros
             ix0[i] = ox * p.stride - p.pad;
-            boff[i] = (long long)b * p.Hi * p.Wi;
-            rowp[i] = nullptr;
+            // the (possibly out-of-image) pixel of tap (0, 0): all 64-bit arithmetic happens here, once.  A k-tile adds one
+            // 32-bit element offset (tap shift + channel offset) shared by the thread's four rows, and tests the bounds with
+            // two unsigned compares -- no multiplies, no branches.  The vector instructions a k-tile spends on addresses
+            // compete with the MFMAs for the SIMD's issue slot: with the full 64-bit index arithmetic per load the 3x3
+            // shapes of ResNet-50 ran 6 % slower (batch 512: 887 -> 833 us over the four of them).
+            rowp[i] = p.in + (((long long)b * p.Hi + (valid ? iy0[i] : 0)) * p.Wi + ix0[i]) * p.Cin;
         }
     }
     const uint16_t* wrow = p.w + (long long)(n0 + row_base) * p.K + chunk * 8;
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
         uint16_t* As_ = smem + (STAGE) * STAGE_ELEMS + wave * 8 * BK;                                                  \
         uint16_t* Bs_ = As_ + BM * BK;                                                                                 \
         const int dy_ = (int8_t)((E) & 0xFF), dx_ = (int8_t)(((E) >> 8) & 0xFF), coff_ = ((E) >> 16) & 0xFFFF;          \
+        const int delta_ = (dy_ * p.Wi + dx_) * p.Cin + coff_;                                                         \
         _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                \
             const uint16_t* src;                                                                                       \
             if (SRC2 && (KT) >= p.nkt1) {                                                                              \
@@ -151,9 +154,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
             } else if (POINTWISE) {                                                                                    \
                 src = rowp[i] ? rowp[i] + (KT) * BK : p.zeros;                                                         \
             } else {                                                                                                   \
-                const int iy = iy0[i] + dy_, ix = ix0[i] + dx_;                                                        \
-                const bool ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;                                          \
-                src = ok ? p.in + ((boff[i] + (long long)iy * p.Wi + ix) * p.Cin + coff_) : p.zeros;                   \
+                const bool ok = (unsigned)(iy0[i] + dy_) < (unsigned)p.Hi && (unsigned)(ix0[i] + dx_) < (unsigned)p.Wi; \
+                src = ok ? rowp[i] + delta_ : p.zeros;                                                                 \
             }                                                                                                          \
             __builtin_amdgcn_global_load_lds((global_cptr)src, (lds_ptr)(As_ + i * 32 * BK), 16, 0, 0);                \
         }                                                                                                              \
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     uint16_t* BsC = smem + T2_E;
     uint16_t* Cs = BsC + BSC_E;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases need no per-load readfirstlane
     const int wr = wave >> 1, wc = wave & 1;   // GEMM 2 / 3
     const int wm = wave & 3, wn = wave >> 2;   // GEMM 1
     int t = blockIdx.x;
