@@ -32,6 +32,10 @@ __shared__ int sd_counters[SDC_N];
 // ... and where its time goes: wave-clock laps (units of 16 cycles), lane 0 of each wave
 enum { SDP_table = 0, SDP_window, SDP_share, SDP_slow, SDP_far, SDP_e2_total, SDP_e1_total, SDP_nearest, SDP_N };
 __shared__ int sd_timers[SDP_N];
+// ... and the kernel's phases (dbg_flags & 128): [0] up to the site list and the mask [1] E1 [2] E2 [3] F [4] G
+__shared__ int sd_phase[8];
+#define SD_HARD_REASON(slot) atomicAdd(&sd_phase[slot], 1)   // [6] edge beyond the table's range [7] table exhausted
+#define SD_PHASE(slot, t) { const long long now_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&sd_phase[slot], (int)((now_ - (t)) >> 4)); (t) = now_; }
 #define SD_NOW() clock64()
 #define SD_LAP(slot, t) { const long long now_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&sd_timers[SDP_##slot], (int)((now_ - (t)) >> 4)); (t) = now_; }
 #endif
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     int* scal = reinterpret_cast<int*>(rmax + Hp);  // [0] n_sites [1] min x [2] max x [3] rows [4] steps [5] err
     unsigned long long* tri_cache = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(scal + 16) + 7) & ~(uintptr_t)7);  // SD_CACHE_SIZE entries
 
+    __shared__ int list_wave_total[DENSIFY_THREADS / 64];
     const int rid = blockIdx.x;
     uint32_t* keys = keys_all + (size_t)rid * H * W;
     const uint8_t* colours = colour_src[rid];
@@ -397,6 +402,9 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
 #if defined(SALVE_PROFILE_WALK)
     if (tid < SDC_N) sd_counters[tid] = 0;
     if (tid < SDP_N) sd_timers[tid] = 0;
+    if (tid < 8) sd_phase[tid] = 0;
+    __syncthreads();
+    long long t_phase = SD_NOW();
 #endif
     for (int i = tid; i < SD_CACHE_SIZE; i += DENSIFY_THREADS) tri_cache[i] = 0ull;
     if (tid < 16) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : (tid == 12 ? H : (tid == 13 ? -1 : 0)));  // [12] min y [13] max y  // [6] site cursor [7] hard sites [8] queued triangles
@@ -473,10 +481,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                 ob = __ballot(site);
                 ne_next = __ballot(ne);
                 if (ob) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&scal[0], __popcll(ob));
-                    base = __shfl(base, 0);
-                    if (site) __hip_atomic_store(sitelist + base + __popcll(ob & ((1ull << lane) - 1ull)), ((uint32_t)y << 16) | (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) atomicAdd(&scal[0], __popcll(ob));
                     lo = min(lo, (seg << 6) + (int)__ffsll((long long)ob) - 1);
                     hi = max(hi, (seg << 6) + 63 - (int)__clzll((long long)ob));
                 }
@@ -514,6 +519,36 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     }
     __syncthreads();
 
+    // ---- phase B2: the list of the sites that need a walk, in raster order (star_local.h: a site between five site
+    //      neighbours owns unit triangles only and is left out -- about half of all sites).  Every thread takes a run of
+    //      consecutive bitmap words; an exclusive scan of the counts gives its place in the list.
+    {
+        const int total = H * wpr, run = (total + DENSIFY_THREADS - 1) / DENSIFY_THREADS;
+        const int w_begin = min(tid * run, total), w_end = min(w_begin + run, total);
+        int cnt = 0;
+        for (int i = w_begin; i < w_end; i++) cnt += __popc(sdl_walk_word(occ, H, wpr, i));
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) list_wave_total[wave] = incl;
+        __syncthreads();
+        int base = incl - cnt;
+        for (int w = 0; w < wave; w++) base += list_wave_total[w];
+        if (tid == DENSIFY_THREADS - 1) scal[14] = base + cnt;
+        for (int i = w_begin; i < w_end; i++) {
+            uint32_t bits = sdl_walk_word(occ, H, wpr, i);
+            const int y = i / wpr, xb = (i - y * wpr) << 5;
+            while (bits) {
+                const int x = xb + __ffs((int)bits) - 1;
+                bits &= bits - 1u;
+                __hip_atomic_store(sitelist + base++, ((uint32_t)y << 16) | (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+
     // ---- phase C: vertical dilation, in place.  A task = one bitmap column word x 16 rows; every task first
     //      pulls its rows plus the halo into registers, then (after a barrier) stores the ORs.
     {
@@ -547,14 +582,17 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
         for (int i = tid; i < H * wpr; i += DENSIFY_THREADS) msk[i] = 0xFFFFFFFFu;
         __syncthreads();
     }
-    const int nsites = scal[0];
+    const int nsites = scal[14];  // sites on the list; scal[0] counts all of them
     // interp_dense_grid_from_sparse early-outs (interpolation_utils.py:39-43): < 4 points, all x equal, all y equal
-    const bool degenerate = nsites < 4 || scal[1] == scal[2] || scal[3] <= 1;
+    const bool degenerate = scal[0] < 4 || scal[1] == scal[2] || scal[3] <= 1;
 
     // the site list and the base image were written by this workgroup through L2: make them visible to all its waves
     wg_barrier_after_global_stores();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
+#if defined(SALVE_PROFILE_WALK)
+    SD_PHASE(0, t_phase);
+#endif
     // ---- phase E: Delaunay stars.
     //      E1: every lane runs the local state machine (star_local.h) and pulls sites from a shared cursor, so lanes
     //          never idle; owned triangles are queued; sites whose star does not fit the window go to the hard list.
@@ -601,7 +639,13 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             }
         }
         if (dbg_stats) atomicAdd(&scal[4], iters);
+#if defined(SALVE_PROFILE_WALK)
+        SD_PHASE(5, t_phase);   // E1 without the wait for the slowest wave
+#endif
         wg_barrier_after_global_stores();  // hard list and triangle queue are complete and in L2
+#if defined(SALVE_PROFILE_WALK)
+        SD_PHASE(1, t_phase);
+#endif
         const int nhard = scal[7];
         const int nq = min(scal[8], H * W);
         int err = 0;
@@ -633,6 +677,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
         }
 #if defined(SALVE_PROFILE_WALK)
         SD_LAP(e2_total, t_e2);
+        SD_PHASE(2, t_phase);
 #endif
         if (err) {
             atomicOr(&scal[5], 1);
@@ -650,6 +695,9 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     // ---- phase G: data pixels outside the mask are 0 in the result (all of them if the interpolation early-outs).
     //      They kept their colour until here because triangles read their vertex colours from the image.
     wg_barrier_after_global_stores();
+#if defined(SALVE_PROFILE_WALK)
+    SD_PHASE(3, t_phase);
+#endif
     for (int i = tid; i < H * wpr; i += DENSIFY_THREADS) {
         uint32_t bits = occ[i] & (degenerate ? 0xFFFFFFFFu : ~msk[i]);
         const int y = i / wpr, xb = (i % wpr) << 5;
@@ -668,7 +716,9 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     if (dbg_stats) {
         __syncthreads();
 #if defined(SALVE_PROFILE_WALK)
-        if (tid < 8) dbg_stats[rid * 8 + tid] = (c.dbg_flags & 64) ? sd_timers[tid] : sd_counters[tid];
+        SD_PHASE(4, t_phase);
+        __syncthreads();
+        if (tid < 8) dbg_stats[rid * 8 + tid] = (c.dbg_flags & 128) ? sd_phase[tid] : (c.dbg_flags & 64) ? sd_timers[tid] : sd_counters[tid];
 #else
         if (tid < 8) dbg_stats[rid * 8 + tid] = tid == 1 ? scal[9] : (tid == 2 ? scal[10] : (tid < 6 ? scal[tid] : scal[tid + 1]));  // [1] sites begun [2] checksum [6] hard sites [7] queued triangles
 #endif

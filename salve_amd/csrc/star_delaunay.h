@@ -537,7 +537,7 @@ SD_FN int sd_star(const SdGrid& g, int sx, int sy, Emit& emit) {
             int px, py;
             if (!sd_apex(g, sx, sy, ax, ay, +1, &px, &py)) break;
             if (!sd_before(sx, sy, px, py)) break;
-            emit(sx, sy, ax, ay, px, py);
+            { long long lap_e = SD_NOW(); emit(sx, sy, ax, ay, px, py); SD_LAP(e1_total, lap_e); }
             if (++steps > SD_MAX_DEGREE) return -1;
             ax = px;
             ay = py;
@@ -553,7 +553,7 @@ SD_FN int sd_star(const SdGrid& g, int sx, int sy, Emit& emit) {
     for (;;) {  // counter-clockwise from the nearest neighbour
         int px, py;
         if (!sd_apex(g, sx, sy, ax, ay, +1, &px, &py)) break;
-        if (sd_before(sx, sy, ax, ay) && sd_before(sx, sy, px, py)) emit(sx, sy, ax, ay, px, py);
+        if (sd_before(sx, sy, ax, ay) && sd_before(sx, sy, px, py)) { long long lap_e = SD_NOW(); emit(sx, sy, ax, ay, px, py); SD_LAP(e1_total, lap_e); }
         if (++steps > SD_MAX_DEGREE) return -1;
         ax = px;
         ay = py;
@@ -565,7 +565,7 @@ SD_FN int sd_star(const SdGrid& g, int sx, int sy, Emit& emit) {
         for (;;) {
             int px, py;
             if (!sd_apex(g, sx, sy, ax, ay, -1, &px, &py)) break;
-            if (sd_before(sx, sy, ax, ay) && sd_before(sx, sy, px, py)) emit(sx, sy, px, py, ax, ay);
+            if (sd_before(sx, sy, ax, ay) && sd_before(sx, sy, px, py)) { long long lap_e = SD_NOW(); emit(sx, sy, px, py, ax, ay); SD_LAP(e1_total, lap_e); }
             if (++steps > SD_MAX_DEGREE) return -1;
             ax = px;
             ay = py;

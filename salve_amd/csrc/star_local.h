@@ -32,7 +32,33 @@ SD_FN bool sdl_bit(const SdGrid& g, int x, int y) {
     return x >= 0 && x < g.W && y >= 0 && y < g.H && ((g.occ[y * g.wpr + (x >> 5)] >> (x & 31)) & 1u);
 }
 
+// Sites that need no walk at all.  If (x+1, y), (x-1, y) and the three pixels above, (x-1 .. x+1, y+1), are all sites, then
+// every triangle that s OWNS (s its raster-first vertex, i.e. its neighbours at angles [0, pi)) is a unit triangle: the edge
+// s -> (1, 0) is Delaunay (adjacent pixels always are), the circle of the unit square on its left holds no lattice point
+// inside, so its apex is (1, 1) or (0, 1) -- both sites, whichever the perturbation ranks first --, and the walk goes on
+// through unit squares until it reaches (-1, 0), which precedes s.  A unit triangle (area 1/2) has no lattice point other
+// than its vertices (Pick), so there is nothing to rasterise: such sites -- about half of them in a texture map -- are
+// left out of the site list.  Word-parallel: bit b of the result = site b of word `c` (row y; l, r its neighbour words,
+// uc / ul / ur the same of row y + 1, zeros beyond the image) is surrounded.  tests/host checks the claim on the host.
+SD_FN uint32_t sdl_surrounded_word(uint32_t c, uint32_t l, uint32_t r, uint32_t uc, uint32_t ul, uint32_t ur) {
+    const uint32_t right = (c >> 1) | (r << 31), left = (c << 1) | (l >> 31);
+    const uint32_t up_right = (uc >> 1) | (ur << 31), up_left = (uc << 1) | (ul >> 31);
+    return c & right & left & uc & up_right & up_left;
+}
+// the sites of bitmap word i = y * wpr + w that DO need a walk
+SD_FN uint32_t sdl_walk_word(const uint32_t* occ, int H, int wpr, int i) {
+    const int y = i / wpr, w = i - y * wpr;
+    const uint32_t c = occ[i];
+    if (c == 0u || y + 1 >= H) return c;
+    const uint32_t l = w > 0 ? occ[i - 1] : 0u, r = w + 1 < wpr ? occ[i + 1] : 0u;
+    const uint32_t uc = occ[i + wpr], ul = w > 0 ? occ[i + wpr - 1] : 0u, ur = w + 1 < wpr ? occ[i + wpr + 1] : 0u;
+    return c & ~sdl_surrounded_word(c, l, r, uc, ul, ur);
+}
+
 enum { SDL_LEAN_CONTINUE = 0, SDL_LEAN_DONE = 1, SDL_LEAN_HARD = 2 };
+#ifndef SD_HARD_REASON
+#define SD_HARD_REASON(slot)
+#endif
 
 struct SdLean {
     int sx, sy;
@@ -96,7 +122,10 @@ SD_FN int sdl_lean_step(SdLean& s, const SdGrid& g, Emit& emit) {
     }
     s.round = 0;
     if (px == SDL_NONE) {
-        if (!sd_side_is_empty(g, s.sx, s.sy, s.sx + s.ax, s.sy + s.ay, s.dir)) return SDL_LEAN_HARD;
+        if (!sd_side_is_empty(g, s.sx, s.sy, s.sx + s.ax, s.sy + s.ay, s.dir)) {
+            SD_HARD_REASON((vx >= -SDT_AMAX && vx <= SDT_AMAX && vy >= -SDT_AMAX && vy <= SDT_AMAX) ? 7 : 6);
+            return SDL_LEAN_HARD;
+        }
         // Hull edge.  A half walk owns nothing beyond it; a full walk goes back to its first neighbour and fans out
         // clockwise until it meets the hull on the other side.
         if (s.half || s.dir < 0) return SDL_LEAN_DONE;

@@ -109,3 +109,44 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
     memcpy(tri_xy, out.data(), out.size() * sizeof(int));
     return nt;
 }
+
+// The sites the kernel leaves out of its list (sdl_walk_word): walk each of them with the general algorithm and count the
+// emitted triangles that are NOT unit triangles (twice the area != 1) -- the claim is that there are none.
+// stats: [0] sites left out, [1] triangles they own.
+extern "C" int star_host_check_left_out(const int* xs, const int* ys, int n, int H, int W, long long* stats) {
+    if (!host_table()) return -3;
+    int wpr = (W + 31) / 32;
+    std::vector<uint32_t> occ((size_t)H * wpr, 0);
+    std::vector<int16_t> rmin(H, (int16_t)W), rmax(H, (int16_t)-1);
+    int bx0 = W, bx1 = -1, by0 = H, by1 = -1;
+    for (int i = 0; i < n; i++) {
+        occ[(size_t)ys[i] * wpr + (xs[i] >> 5)] |= 1u << (xs[i] & 31);
+        if (xs[i] < rmin[ys[i]]) rmin[ys[i]] = (int16_t)xs[i];
+        if (xs[i] > rmax[ys[i]]) rmax[ys[i]] = (int16_t)xs[i];
+        if (xs[i] < bx0) bx0 = xs[i];
+        if (xs[i] > bx1) bx1 = xs[i];
+        if (ys[i] < by0) by0 = ys[i];
+        if (ys[i] > by1) by1 = ys[i];
+    }
+    SdGrid g = {H, W, wpr, occ.data(), rmin.data(), rmax.data(), 0, 1, host_table(), bx0, bx1, by0, by1, nullptr};
+    long long left_out = 0, owned = 0;
+    int bad = 0;
+    for (int i = 0; i < H * wpr; i++) {
+        uint32_t skip = occ[i] & ~sdl_walk_word(occ.data(), H, wpr, i);
+        const int y = i / wpr, xb = (i % wpr) << 5;
+        for (int b = 0; b < 32; b++) {
+            if (!((skip >> b) & 1u)) continue;
+            left_out++;
+            std::vector<int> mine;
+            Collect cm = {&mine};
+            if (sd_star(g, xb + b, y, cm) < 0) return -1;
+            for (size_t t = 0; t + 5 < mine.size(); t += 6) {
+                owned++;
+                const long long a2 = (long long)(mine[t + 2] - mine[t]) * (mine[t + 5] - mine[t + 1]) - (long long)(mine[t + 3] - mine[t + 1]) * (mine[t + 4] - mine[t]);
+                if (a2 != 1 && a2 != -1) bad++;
+            }
+        }
+    }
+    if (stats) { stats[0] = left_out; stats[1] = owned; }
+    return bad;
+}

@@ -113,3 +113,44 @@ def test_realistic_render_sites(lib):
     assert got == ref
     assert stats[1] < 0.05 * len(sp)  # only a few per cent of the sites need the general walk
     assert run(lib.star_host_triangulate, sp, 501, 501)[0] == ref
+
+
+def left_out(lib, pts, H, W):
+    xs = np.ascontiguousarray(pts[:, 0], dtype=np.int32)
+    ys = np.ascontiguousarray(pts[:, 1], dtype=np.int32)
+    stats = np.zeros(4, dtype=np.int64)
+    bad = lib.star_host_check_left_out(xs.ctypes.data_as(ctypes.c_void_p), ys.ctypes.data_as(ctypes.c_void_p), len(xs), H, W,
+                                       stats.ctypes.data_as(ctypes.c_void_p))
+    return bad, int(stats[0]), int(stats[1])
+
+
+def test_sites_left_out_of_the_list_own_unit_triangles_only(lib):
+    """star_local.h sdl_walk_word: a site between five site neighbours is not walked by the kernel.  Every triangle such a
+    site owns must be a unit triangle (nothing to rasterise) -- on dense random sets, full lattices, image borders (the
+    bitmap word boundaries at x = 31 / 32 / 63 / 64 included) and a real render's sites."""
+    lib.star_host_use_table(1)
+    rng = np.random.default_rng(23)
+    seen = 0
+    for _ in range(120):
+        G = int(rng.integers(8, 100))
+        dens = rng.uniform(0.5, 0.98)
+        pts = np.argwhere(rng.random((G, G)) < dens)[:, ::-1].copy()
+        if len(pts) < 4 or bo._is_degenerate(pts):
+            continue
+        bad, n_out, owned = left_out(lib, pts, G, G)
+        assert bad == 0
+        assert owned >= n_out          # at least one owned triangle each: (s, right neighbour, one of the two above)
+        seen += n_out
+    assert seen > 20000
+    yy, xx = np.mgrid[0:40, 0:70]
+    full = np.stack([xx.ravel(), yy.ravel()], 1)
+    bad, n_out, _ = left_out(lib, full, 40, 70)
+    assert bad == 0 and n_out == 39 * 68   # every site with both horizontal neighbours and a row above
+    hyp = synthetic.make_hypotheses(16, 2, seed=0)
+    p0 = synthetic.make_pano(0)
+    a = bo.xyzrgb_from_arrays(p0[1], p0[0], bo.floor_ceiling_z_range("floor"))
+    a, _ = bo.pose_pair(a, a[:1], hyp.R[0], hyp.t[0])
+    _, img_xy = bo.bev_pixel_indices(a[:, :3])
+    sites = np.unique(img_xy, axis=0)
+    bad, n_out, _ = left_out(lib, sites, 501, 501)
+    assert bad == 0 and n_out > 0.3 * len(sites)

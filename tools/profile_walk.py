@@ -31,5 +31,12 @@ ras.cfg.reserved1 = 64
 bev, dbg = ras.render(d_rgb, d_depth, hd, n, debug=True)
 torch.cuda.synchronize()
 st = dbg.stats.cpu().numpy().astype(np.float64) * 16
-names = ["table", "window", "share", "slow", "far", "e2_total", "e1_total", "nearest"]
+names = ["table", "window", "share", "slow", "far", "e2_total", "emit (E2 raster)", "nearest"]
 print("wave-cycles per render (sum over 8 waves):", {k: round(v) for k, v in zip(names, st.mean(0))})
+ras.cfg.reserved1 = 128
+bev, dbg = ras.render(d_rgb, d_depth, hd, n, debug=True)
+torch.cuda.synchronize()
+st = dbg.stats.cpu().numpy().astype(np.float64) * 16
+st[:, 6:] /= 16
+names = ["A-D (sites, mask)", "E1 wait", "E2", "F", "G", "E1 (own work)", "hard: long edge", "hard: table exhausted"]
+print("phases, wave-cycles per render (sum over 8 waves):", {k: round(v) for k, v in zip(names, st.mean(0))})
