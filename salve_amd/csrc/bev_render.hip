@@ -28,7 +28,11 @@
 // development build: count the general walk's work in LDS (read back through dbg_stats slots 1, 2, 3)
 enum { SDC_apex = 0, SDC_apex_slow, SDC_apex_far, SDC_rows, SDC_bits, SDC_exact, SDC_apex_table, SDC_apex_cached, SDC_N };
 __shared__ int sd_counters[SDC_N];
+#if defined(SALVE_PROFILE_NO_COUNT)   // timers only: the counters' LDS atomics (one per row and per bit) distort the laps
+#define SD_COUNT(c)
+#else
 #define SD_COUNT(c) atomicAdd(&sd_counters[SDC_##c], 1)
+#endif
 // ... and where its time goes: wave-clock laps (units of 16 cycles), lane 0 of each wave
 enum { SDP_table = 0, SDP_window, SDP_share, SDP_slow, SDP_far, SDP_e2_total, SDP_e1_total, SDP_nearest, SDP_N };
 __shared__ int sd_timers[SDP_N];
@@ -52,6 +56,14 @@ constexpr int PTS_PER_THREAD = 4;
 constexpr int DENSIFY_THREADS = 512;
 constexpr int MASK_ROWS_PER_TASK = 16;
 constexpr int MASK_MAX_HALF = 8;
+#ifndef SALVE_E2_GROUP
+#define SALVE_E2_GROUP 64
+#endif
+#ifndef SALVE_HARD_RUN
+#define SALVE_HARD_RUN 8
+#endif
+constexpr int E2_GROUP = SALVE_E2_GROUP;   // lanes that share the general walk of one hard site (power of two, <= 64)
+constexpr int HARD_RUN = SALVE_HARD_RUN;   // consecutive hard-list entries a group takes at a time
 // z-order key of a pixel: (unit slice + 1) << 21 | point index.  atomicMax keeps the highest slice and, within it, the
 // last point in raster order (zorder_utils.py:10-83 + "last index wins" of the sparse image); 0 = no point.  The
 // colour is NOT in the key: the densify kernel fetches it from the point's source array by index.
@@ -652,22 +664,26 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
 #if defined(SALVE_PROFILE_WALK)
         long long t_e2 = SD_NOW();
 #endif
-        {   // E2: one wavefront per hard site; its row sweeps and its rasterisation are shared by the 64 lanes
+        {   // E2: one group of E2_GROUP lanes per hard site; its row sweeps, candidate probes and its rasterisation are shared
+            //     by the group's lanes.  The group is the whole wavefront: with several walks side by side in one wavefront
+            //     (16- or 32-lane groups) the walks diverge -- one takes a table hit while its neighbour sweeps -- and the
+            //     wavefront pays for every path in turn.  Measured, general walk per render (box / cluttered scene):
+            //     64 lanes 2.6 / 4.0 us, 32 lanes 2.9 / 4.2 us, 16 lanes 4.0 / 5.1 us, 8 lanes 8.9 / 8.5 us.
             SdGrid gw = g;
-            gw.lane = lane;
-            gw.nlanes = 64;
+            gw.lane = lane & (E2_GROUP - 1);
+            gw.nlanes = E2_GROUP;
+            gw.gbase = lane & ~(E2_GROUP - 1);
             RasterEmit rw = raster;
-            rw.lane = lane;
-            rw.nlanes = 64;
-            // A wavefront takes HARD_RUN consecutive list entries at a time: neighbours in the list are neighbours in the
-            // image (the lean walk met them in raster order), and one wave walking them one after the other finds the
-            // triangles of the previous site in the cache instead of racing another wave for them.
-            constexpr int HARD_RUN = 8;
+            rw.lane = gw.lane;
+            rw.nlanes = E2_GROUP;
+            // A group takes HARD_RUN consecutive list entries at a time: neighbours in the list are neighbours in the
+            // image (the lean walk met them in raster order), and one group walking them one after the other finds the
+            // triangles of the previous site in the cache instead of racing another group for them.
             const int nh = (c.dbg_flags & 4) ? 0 : nhard;
             for (;;) {
                 int i0 = 0;
-                if (lane == 0) i0 = atomicAdd(&scal[11], HARD_RUN);
-                i0 = __builtin_amdgcn_readfirstlane(i0);
+                if (gw.lane == 0) i0 = atomicAdd(&scal[11], HARD_RUN);
+                i0 = __shfl(i0, gw.gbase);
                 if (i0 >= nh) break;
                 for (int i = i0; i < min(i0 + HARD_RUN, nh); i++) {
                     const uint32_t s = __hip_atomic_load(hardlist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -682,7 +698,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
         if (err) {
             atomicOr(&scal[5], 1);
             // a star walk that did not close: the image of this render is incomplete -- tell the host (salve_hip.h: status word)
-            if (status && lane == 0) atomicOr(status, SALVE_STATUS_WALK_FAILED);
+            if (status && (lane & (E2_GROUP - 1)) == 0) atomicOr(status, SALVE_STATUS_WALK_FAILED);
         }
         for (int i = tid; i < ((c.dbg_flags & 8) ? 0 : nq); i += DENSIFY_THREADS) {
             const unsigned long long e = __hip_atomic_load(triq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -41,6 +41,9 @@ struct SdGrid {
     // (0 = empty).  Every triangle found serves three directed edges; along the outline of the point cloud, where the
     // general walk is needed, neighbouring sites ask for the same triangles: about half of the sweeps are avoided.
     unsigned long long* cache;  // or nullptr; requires H, W <= 1024
+    // The lanes that share a walk are an aligned group of nlanes (a power of two) consecutive lanes of the wavefront
+    // starting at lane gbase -- the whole wavefront (64, 0) or a part of it, several walks per wavefront then.
+    int gbase;
 };
 
 #define SD_CACHE_SIZE 1536
@@ -96,6 +99,18 @@ SD_FN bool sd_occupied(const SdGrid& g, int x, int y) {
 SD_FN int32_t sd_orient(int ax, int ay, int bx, int by, int cx, int cy) {
     return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Votes and broadcasts inside the group of lanes that shares a walk.  Control flow is uniform within a group, never
+// between groups: a ballot taken under divergence simply lacks the other groups' bits, and a group only reads its own.
+SD_FN unsigned long long sd_group_ballot(const SdGrid& g, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    return g.nlanes == 64 ? m : (m >> g.gbase) & ((1ull << g.nlanes) - 1ull);
+}
+SD_FN int sd_group_read(const SdGrid& g, int v, int l) {  // v of the group's lane l (l: the same in all lanes of the group)
+    return g.nlanes == 64 ? __builtin_amdgcn_readlane(v, l) : __shfl(v, g.gbase + l);
+}
+#endif
 
 // True if no site can lie strictly on side dir of s->a because the bounding box of all sites does not reach there:
 // then s->a is a hull edge.  Settles, without a sweep, the edges along the border of a cloud that was clipped to the
@@ -195,15 +210,15 @@ SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (g.nlanes > 1) {
             int32_t m = best;
-            for (int off = 32; off >= 1; off >>= 1) {
+            for (int off = g.nlanes >> 1; off >= 1; off >>= 1) {
                 const int32_t o = __shfl_xor(m, off);
                 m = o < m ? o : m;
             }
             if (m != INT32_MAX) {  // the lowest lane holding the minimum
-                const unsigned long long who = __ballot(best == m);
+                const unsigned long long who = sd_group_ballot(g, best == m);
                 const int l = (int)__ffsll((long long)who) - 1;
-                bx = __builtin_amdgcn_readlane(bx, l);
-                by = __builtin_amdgcn_readlane(by, l);
+                bx = sd_group_read(g, bx, l);
+                by = sd_group_read(g, by, l);
             }
             best = m;
         }
@@ -382,24 +397,24 @@ SD_FN void sd_share_best(const SdGrid& g, const SdEdge& e, SdBest* best, int* sh
 #if defined(__HIP_DEVICE_COMPILE__)
     if (g.nlanes > 1) {
         // nothing to merge if no lane improved on the candidate all lanes agreed on last time
-        const unsigned long long changed = __ballot(best->px >= 0 && (best->px != *shared_x || best->py != *shared_y));
+        const unsigned long long changed = sd_group_ballot(g, best->px >= 0 && (best->px != *shared_x || best->py != *shared_y));
         if (changed == 0ull) return;
         // contenders: the lanes that changed (each of their candidates beats the one shared so far); if many did, a
         // float minimum over the wave thins them out first
         unsigned long long cont = changed;
         if (__popcll(changed) > 4) {
             float m = best->px >= 0 ? best->lam : 3.0e38f;
-            for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+            for (int off = g.nlanes >> 1; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off));
             const float tol = 2.f * SD_LAM_TOL * fabsf(m) + 1e-30f;
-            cont = __ballot(best->px >= 0 && best->lam <= m + 2.f * tol);
+            cont = sd_group_ballot(g, best->px >= 0 && best->lam <= m + 2.f * tol);
         }
         SdBest w;
         w.px = -1; w.py = -1; w.lam = 0.f; w.ox = w.oy = w.rpad = w.r2 = 0.f; w.bounded = false;
         while (cont) {
             const int l = (int)__ffsll((long long)cont) - 1;
             cont &= cont - 1ull;
-            const int ox = __builtin_amdgcn_readlane(best->px, l), oy = __builtin_amdgcn_readlane(best->py, l);
-            const float ol = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(best->lam), l));
+            const int ox = sd_group_read(g, best->px, l), oy = sd_group_read(g, best->py, l);
+            const float ol = __uint_as_float((unsigned)sd_group_read(g, (int)__float_as_uint(best->lam), l));
             if (sd_beats(e, w, ox, oy, ol)) { w.px = ox; w.py = oy; w.lam = ol; }
         }
         sd_best_set(*best, e, w.px, w.py, w.lam);
@@ -429,11 +444,11 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
             const int8_t* row = g.tab + sdt_index(vx, vy) * (SDT_LEN * 2);
             int hit = -1;
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (g.nlanes == 64) {  // one candidate per lane and round, the lowest occupied entry wins
-                for (int k0 = 0; k0 < SDT_LEN && hit < 0; k0 += 64) {
+            if (g.nlanes > 1) {  // one candidate per lane and round, the lowest occupied entry wins
+                for (int k0 = 0; k0 < SDT_LEN && hit < 0; k0 += g.nlanes) {
                     const int k = k0 + g.lane;
                     const bool b = k < SDT_LEN && sd_occupied(g, ox + row[2 * (k & (SDT_LEN - 1))], oy + row[2 * (k & (SDT_LEN - 1)) + 1]);
-                    const unsigned long long m = __ballot(b);
+                    const unsigned long long m = sd_group_ballot(g, b);
                     if (m) hit = k0 + (int)__ffsll((long long)m) - 1;
                 }
             } else
@@ -471,6 +486,9 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     //    A window that covers the whole bounding box and is still empty proves s->a a hull edge.
     int M = SD_WINDOW_MARGIN;
     int wy0, wy1, wx0, wx1;
+#if defined(SD_ABL_NO_WINDOW)   // development: timing only -- every query that reaches the sweeps is answered "hull edge"
+    if (g.nlanes > 1) return false;
+#endif
     for (;;) {
         wy0 = (sy < ay ? sy : ay) - M; wy1 = (sy > ay ? sy : ay) + M;
         wx0 = (sx < ax ? sx : ax) - M; wx1 = (sx > ax ? sx : ax) + M;
@@ -503,7 +521,11 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
             if (fy1 < (float)cy1) cy1 = (int)fy1;
             if (fx1 < (float)cx1) cx1 = (int)fx1;
         }
+#if defined(SD_ABL_NO_SLOW)   // development (tools/densify_ablation.py): timing only, the result is wrong
+        if (false) {
+#else
         if (cy1 > wy1 || cy0 < wy0 || cx0 < wx0 || cx1 > wx1) {
+#endif
             SD_COUNT(apex_slow);
             // one sweep over the circle's rows: what the window already covered is cut away by the circle, cheaply
             sd_scan_rows<true>(g, edge, cy0, cy1, 1, cx0, cx1, &best);

@@ -25,6 +25,6 @@ def timed(flags, reps=3):
     return best * 1e6 / n
 full = timed(0)
 print(f"{scene}: scatter + densify, {n} renders per launch: {full:.2f} us per render")
-for name, fl in (("without the general walk (E2)", 4), ("without triangle rasterisation (F)", 8), ("without E2 and F", 12), ("without any star walk (E1, E2, F)", 1)):
+for name, fl in (("E2 walks but does not rasterise", 2), ("without the general walk (E2)", 4), ("without triangle rasterisation (F)", 8), ("without E2 and F", 12), ("without any star walk (E1, E2, F)", 1)):
     t = timed(fl)
     print(f"  {name:40s} {t:.2f} us   (-{full - t:.2f})")

@@ -7,7 +7,7 @@ sys.path.insert(0, str(ROOT))
 SO = ROOT / "tools" / "libsalve_profile.so"
 if "--build-only" in sys.argv:
     srcs = sorted(str(p) for p in (ROOT / "salve_amd" / "csrc").glob("*.hip"))
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-DSALVE_PROFILE_WALK",
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-DSALVE_PROFILE_WALK"] + (["-DSALVE_PROFILE_NO_COUNT"] if "--no-count" in sys.argv else []) + [
                     "-fPIC", "-shared", "-o", str(SO)] + srcs, check=True)
     sys.exit(0)
 import numpy as np, torch
