@@ -48,7 +48,8 @@ def counters(d):
     return ks[-(len(ks) // 3):]
 a, b, c = counters("sq1"), counters("sq2"), counters("sq3")
 assert len(a) == len(b) == len(c)
-tr = [l for l in open(SRC / "trace_report.txt")] if (SRC / "trace_report.txt").exists() else []
+import subprocess
+tr = subprocess.run([sys.executable, str(ROOT / "tools" / "trace_resnet_report.py"), str(SRC / "trace")], capture_output=True, text=True).stdout.splitlines()
 out = ["# SQ counters of the verifier, round 2 (MI355X, rocprofv3 --pmc, --kernel-trace only; tools/trace_resnet.py: ResNet-50, 6 channels, batch 512)",
        "", "Passes: (1) SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES,",
        "(2) SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM, (3) GRBM_GUI_ACTIVE.",
