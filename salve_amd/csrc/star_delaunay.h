@@ -521,6 +521,22 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
             if (fy1 < (float)cy1) cy1 = (int)fy1;
             if (fx1 < (float)cx1) cx1 = (int)fx1;
         }
+        if (best.lam <= 0.f) {
+            // The centre lies on the far side of the edge (or on it): what remains to search is the MINOR segment of
+            // the disc, every point of which is within the sagitta h of the chord s-a and projects onto it -- so it
+            // lies in the chord's bounding box widened by h.  For the slivers along a straight outline (three nearly
+            // collinear sites, a circle hundreds of pixels across) that is a few rows instead of the whole image.
+            // h = r - d = (|a|/2)^2 / (r + d), d = |lambda| |a| the centre's distance from the chord (no cancellation).
+            // (Better candidates found during the sweep have their segment on this side INSIDE this one: the circles
+            // through s and a are nested on either side of the chord, ordered by lambda.)
+            const float h = 0.25f * edge.a2 / (SD_SQRT(best.r2) + fabsf(best.lam) * SD_SQRT(edge.a2)) * 1.0001f + 2.0f;
+            const float ly0 = floorf((float)(sy < ay ? sy : ay) - h), ly1 = ceilf((float)(sy > ay ? sy : ay) + h);
+            const float lx0 = floorf((float)(sx < ax ? sx : ax) - h), lx1 = ceilf((float)(sx > ax ? sx : ax) + h);
+            if (ly0 > (float)cy0) cy0 = (int)ly0;
+            if (lx0 > (float)cx0) cx0 = (int)lx0;
+            if (ly1 < (float)cy1) cy1 = (int)ly1;
+            if (lx1 < (float)cx1) cx1 = (int)lx1;
+        }
 #if defined(SD_ABL_NO_SLOW)   // development (tools/densify_ablation.py): timing only, the result is wrong
         if (false) {
 #else
