@@ -56,6 +56,7 @@ constexpr int PTS_PER_THREAD = 4;
 constexpr int DENSIFY_THREADS = 512;
 constexpr int MASK_ROWS_PER_TASK = 16;
 constexpr int MASK_MAX_HALF = 8;
+constexpr int N_SCAL = 24;   // int32 scalars of a render in LDS (bev_densify_kernel: scal[])
 #ifndef SALVE_E2_GROUP
 #define SALVE_E2_GROUP 64
 #endif
@@ -331,15 +332,53 @@ struct RasterEmit {
 
 // Emit functor of the local star walk: owned triangles go to a per-render queue (8 bytes each: the site, and the two
 // other vertices relative to it) and are rasterised afterwards by all lanes at once.
+//
+// Three queues in one array.  Of the triangles that have anything to fill, two in three have twice-the-area 2: by Pick they
+// hold exactly one lattice point besides their vertices, the MIDPOINT of their one edge with an even difference vector, and
+// its colour is the floor of the mean of that edge's end points (barycentric weights 1 : 1 : 0 over 2).  Those go to the
+// second third of the array as (midpoint, half edge vector) and are filled by a loop of a dozen instructions per lane; in
+// one list with the general triangles every wavefront would run at the pace of its general ones.  Another fifth has
+// twice-the-area 3 and one interior point, its centroid (third queue).
 struct QueueEmit {
     unsigned long long* queue;
-    int* counter;  // LDS
-    int capacity;
+    int* counter;  // LDS: general triangles, [0, capacity)
+    int capacity;  // of each third
     RasterEmit fallback;
+    int* counter_mid;  // LDS: midpoint triangles, [capacity, 2 capacity)
+    int* counter_cen;  // LDS: centroid triangles, [2 capacity, 3 capacity)
     __device__ __forceinline__ void operator()(int ax, int ay, int bx, int by, int cx, int cy) const {
         // most triangles of a densely covered region are unit lattice triangles (twice the area = 1): no lattice point
         // other than the vertices lies in them (Pick), nothing to interpolate
-        if (sd_orient(ax, ay, bx, by, cx, cy) <= 1) return;
+        const int32_t area = sd_orient(ax, ay, bx, by, cx, cy);
+        if (area <= 1) return;
+        if (area == 2) {
+            int px = cx, py = cy, qx = ax, qy = ay;                                  // edge c-a unless ...
+            if ((((bx - ax) | (by - ay)) & 1) == 0) { px = ax; py = ay; qx = bx; qy = by; }
+            else if ((((cx - bx) | (cy - by)) & 1) == 0) { px = bx; py = by; qx = cx; qy = cy; }
+            const int slot = atomicAdd(counter_mid, 1);
+            if (slot < capacity) {
+                const int mx = (px + qx) >> 1, my = (py + qy) >> 1;
+                const uint32_t half = (uint32_t)((qx - mx) & 0xFF) | ((uint32_t)((qy - my) & 0xFF) << 8);
+                __hip_atomic_store(queue + capacity + slot, ((unsigned long long)half << 32) | ((uint32_t)my << 16) | (uint32_t)mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                fallback(ax, ay, bx, by, cx, cy);
+            }
+            return;
+        }
+        if (area == 3 && (ax + bx + cx) % 3 == 0 && (ay + by + cy) % 3 == 0) {
+            // twice-the-area 3 with a lattice centroid: that is the triangle's one interior point (and its boundary holds
+            // no lattice point), weights 1 : 1 : 1 over 3.  (The other kind of area 3 has two points on one edge: general.)
+            const int slot = atomicAdd(counter_cen, 1);
+            if (slot < capacity) {
+                const int mx = (ax + bx + cx) / 3, my = (ay + by + cy) / 3;
+                const uint32_t rel = (uint32_t)((ax - mx) & 0xFF) | ((uint32_t)((ay - my) & 0xFF) << 8) |
+                                     ((uint32_t)((bx - mx) & 0xFF) << 16) | ((uint32_t)((by - my) & 0xFF) << 24);
+                __hip_atomic_store(queue + 2 * capacity + slot, ((unsigned long long)rel << 32) | ((uint32_t)my << 16) | (uint32_t)mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                fallback(ax, ay, bx, by, cx, cy);
+            }
+            return;
+        }
         const int slot = atomicAdd(counter, 1);
         if (slot < capacity) {
             const uint32_t rel = (uint32_t)((bx - ax) & 0xFF) | ((uint32_t)((by - ay) & 0xFF) << 8) |
@@ -397,7 +436,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     const int Hp = (H + 1) & ~1;  // keep the int32 scalars 4-byte aligned behind the two int16 arrays
     int16_t* rmax = rmin + Hp;
     int* scal = reinterpret_cast<int*>(rmax + Hp);  // [0] n_sites [1] min x [2] max x [3] rows [4] steps [5] err
-    unsigned long long* tri_cache = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(scal + 16) + 7) & ~(uintptr_t)7);  // SD_CACHE_SIZE entries
+    unsigned long long* tri_cache = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(scal + N_SCAL) + 7) & ~(uintptr_t)7);  // SD_CACHE_SIZE entries
 
     __shared__ int list_wave_total[DENSIFY_THREADS / 64];
     const int rid = blockIdx.x;
@@ -419,7 +458,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     long long t_phase = SD_NOW();
 #endif
     for (int i = tid; i < SD_CACHE_SIZE; i += DENSIFY_THREADS) tri_cache[i] = 0ull;
-    if (tid < 16) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : (tid == 12 ? H : (tid == 13 ? -1 : 0)));  // [12] min y [13] max y  // [6] site cursor [7] hard sites [8] queued triangles
+    if (tid < N_SCAL) scal[tid] = (tid == 1) ? W : (tid == 2 ? -1 : (tid == 12 ? H : (tid == 13 ? -1 : 0)));  // [12] min y [13] max y  // [6] site cursor [7] hard sites [8] queued triangles
     __syncthreads();
 
     // ---- phase B: bitmaps by wave ballot (no LDS atomics), row extents, compact site list.
@@ -613,7 +652,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     if (!degenerate && !(c.dbg_flags & 1)) {
         SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13], (H <= 1024 && W <= 1024 && !(c.dbg_flags & 256)) ? tri_cache : nullptr};
         RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (c.dbg_flags & 2) != 0};
-        QueueEmit qemit = {triq, &scal[8], H * W, raster};
+        QueueEmit qemit = {triq, &scal[8], (H * W) / 3, raster, &scal[15], &scal[16]};
         SdLean st;
         bool active = false, exhausted = false;
         int iters = 0;
@@ -659,7 +698,8 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
         SD_PHASE(1, t_phase);
 #endif
         const int nhard = scal[7];
-        const int nq = min(scal[8], H * W);
+        const int qcap = (H * W) / 3;
+        const int nq = min(scal[8], qcap), nmid = min(scal[15], qcap), ncen = min(scal[16], qcap);
         int err = 0;
 #if defined(SALVE_PROFILE_WALK)
         long long t_e2 = SD_NOW();
@@ -706,6 +746,34 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             const uint32_t rel = (uint32_t)(e >> 32);
             raster(ax, ay, ax + (int8_t)(rel & 0xFF), ay + (int8_t)((rel >> 8) & 0xFF), ax + (int8_t)((rel >> 16) & 0xFF),
                    ay + (int8_t)(rel >> 24));
+        }
+        for (int i = tid; i < ((c.dbg_flags & (8 | 2)) ? 0 : nmid); i += DENSIFY_THREADS) {   // midpoint triangles
+            const unsigned long long e = __hip_atomic_load(triq + qcap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int mx = (int)(e & 0xFFFFu), my = (int)((e >> 16) & 0xFFFFu);
+            const int dx = (int8_t)((e >> 32) & 0xFF), dy = (int8_t)((e >> 40) & 0xFF);
+            if (!(((msk[my * wpr + (mx >> 5)] & ~occ[my * wpr + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
+            const uint32_t cp = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - (my - dy) : my - dy) * W + (mx - dx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t cq = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - (my + dy) : my + dy) * W + (mx + dx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // floor((p + q) / 2) in each of the three colour bytes at once
+            bev[(size_t)(flip >= 0 ? flip - my : my) * W + mx] = (((cp & 0xFEFEFEu) >> 1) + ((cq & 0xFEFEFEu) >> 1) + (cp & cq & 0x010101u));
+        }
+        for (int i = tid; i < ((c.dbg_flags & (8 | 2)) ? 0 : ncen); i += DENSIFY_THREADS) {   // centroid triangles
+            const unsigned long long e = __hip_atomic_load(triq + 2 * qcap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int mx = (int)(e & 0xFFFFu), my = (int)((e >> 16) & 0xFFFFu);
+            if (!(((msk[my * wpr + (mx >> 5)] & ~occ[my * wpr + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
+            const int ax = mx + (int8_t)((e >> 32) & 0xFF), ay = my + (int8_t)((e >> 40) & 0xFF);
+            const int bx = mx + (int8_t)((e >> 48) & 0xFF), by = my + (int8_t)((e >> 56) & 0xFF);
+            const int cx = 3 * mx - ax - bx, cy = 3 * my - ay - by;
+            const uint32_t ca = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - ay : ay) * W + ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t cb = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - by : by) * W + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t cc = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - cy : cy) * W + cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t out = 0;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const uint32_t sum = ((ca >> (8 * ch)) & 255u) + ((cb >> (8 * ch)) & 255u) + ((cc >> (8 * ch)) & 255u);
+                out |= ((sum * 0xAAABu) >> 17) << (8 * ch);   // floor(sum / 3), exact below 2^16
+            }
+            bev[(size_t)(flip >= 0 ? flip - my : my) * W + mx] = out;
         }
     }
     // ---- phase G: data pixels outside the mask are 0 in the result (all of them if the interpolation early-outs).
@@ -933,7 +1001,7 @@ bool make_devcfg(const salve_bev_config_t* cfg, DevCfg* d) {
 }
 
 size_t densify_lds_bytes(const DevCfg& d) {
-    return (size_t)2 * d.H * d.wpr * 4 + (size_t)2 * ((d.H + 1) & ~1) * 2 + 64 + 8 + (size_t)SD_CACHE_SIZE * 8;
+    return (size_t)2 * d.H * d.wpr * 4 + (size_t)2 * ((d.H + 1) & ~1) * 2 + N_SCAL * 4 + 8 + (size_t)SD_CACHE_SIZE * 8;
 }
 
 }  // namespace
