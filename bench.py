@@ -38,7 +38,7 @@ GFLOP_PER_SAMPLE = {50: 8.410, 152: 23.259, 18: 3.6}  # SURVEY 8d (2 x MAC, 6 in
 # HBM bytes per render of the WHOLE rasteriser (key-image clear + both scatter passes + densify) from the PMC counters
 # (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes): see RASTERISER_TRAFFIC_SOURCE.  The narrow (4 B / lane) loads are
 # uncalibrated for FETCH_SIZE, so the read side is a lower bound.
-RASTERISER_TRAFFIC_BYTES_PER_RENDER = 5.83e6
+RASTERISER_TRAFFIC_BYTES_PER_RENDER = 5.56e6
 RASTERISER_TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.md"
 
 

@@ -330,6 +330,14 @@ struct RasterEmit {
     }
 };
 
+// Site list, hard-site list and triangle queues are written and read by ONE workgroup: plain stores (write-back in this
+// XCD's L2), made visible to the workgroup's other waves by wg_barrier_after_global_stores(), read back past the L1.  As
+// agent-scope stores they were written THROUGH to memory -- the L2s of the eight XCDs are not coherent with each other --,
+// one 32-byte sector per 4- or 8-byte store whenever the lanes of an instruction did not fill sectors: 1.3 MB of HBM writes
+// per render for a 0.2 MB site list (profiles/r02_pmc_traffic.md).
+template <class T>
+__device__ __forceinline__ void store_wb(T* p, T v) { *p = v; }
+
 // Emit functor of the local star walk: owned triangles go to a per-render queue (8 bytes each: the site, and the two
 // other vertices relative to it) and are rasterised afterwards by all lanes at once.
 //
@@ -359,7 +367,7 @@ struct QueueEmit {
             if (slot < capacity) {
                 const int mx = (px + qx) >> 1, my = (py + qy) >> 1;
                 const uint32_t half = (uint32_t)((qx - mx) & 0xFF) | ((uint32_t)((qy - my) & 0xFF) << 8);
-                __hip_atomic_store(queue + capacity + slot, ((unsigned long long)half << 32) | ((uint32_t)my << 16) | (uint32_t)mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                store_wb(queue + capacity + slot, ((unsigned long long)half << 32) | ((uint32_t)my << 16) | (uint32_t)mx);
             } else {
                 fallback(ax, ay, bx, by, cx, cy);
             }
@@ -373,7 +381,7 @@ struct QueueEmit {
                 const int mx = (ax + bx + cx) / 3, my = (ay + by + cy) / 3;
                 const uint32_t rel = (uint32_t)((ax - mx) & 0xFF) | ((uint32_t)((ay - my) & 0xFF) << 8) |
                                      ((uint32_t)((bx - mx) & 0xFF) << 16) | ((uint32_t)((by - my) & 0xFF) << 24);
-                __hip_atomic_store(queue + 2 * capacity + slot, ((unsigned long long)rel << 32) | ((uint32_t)my << 16) | (uint32_t)mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                store_wb(queue + 2 * capacity + slot, ((unsigned long long)rel << 32) | ((uint32_t)my << 16) | (uint32_t)mx);
             } else {
                 fallback(ax, ay, bx, by, cx, cy);
             }
@@ -383,7 +391,7 @@ struct QueueEmit {
         if (slot < capacity) {
             const uint32_t rel = (uint32_t)((bx - ax) & 0xFF) | ((uint32_t)((by - ay) & 0xFF) << 8) |
                                  ((uint32_t)((cx - ax) & 0xFF) << 16) | ((uint32_t)((cy - ay) & 0xFF) << 24);
-            __hip_atomic_store(queue + slot, ((unsigned long long)rel << 32) | ((uint32_t)ay << 16) | (uint32_t)ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            store_wb(queue + slot, ((unsigned long long)rel << 32) | ((uint32_t)ay << 16) | (uint32_t)ax);
         } else {
             fallback(ax, ay, bx, by, cx, cy);  // queue full (cannot happen below ~50 % occupancy): rasterise in place
         }
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             while (bits) {
                 const int x = xb + __ffs((int)bits) - 1;
                 bits &= bits - 1u;
-                __hip_atomic_store(sitelist + base++, ((uint32_t)y << 16) | (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                store_wb(sitelist + base++, ((uint32_t)y << 16) | (uint32_t)x);
             }
         }
     }
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                         const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (dbg_stats) { atomicAdd(&scal[9], 1); atomicAdd(&scal[10], (int)(s & 0xFFFFu) + (int)(s >> 16)); }
                         if (sdl_lean_begin(st, g, (int)(s & 0xFFFFu), (int)(s >> 16)) == SDL_LEAN_CONTINUE) active = true;
-                        else __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else store_wb(hardlist + atomicAdd(&scal[7], 1), s);
                     }
                 }
             } else if (busy == 0ull) {
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                     {
                         dbg_mask[((size_t)rid * H + st.sy) * W + st.sx] = (uint8_t)((r == SDL_LEAN_HARD ? 200 : 100) + min(st.deg, 50));
                     }
-                    if (r == SDL_LEAN_HARD) __hip_atomic_store(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (r == SDL_LEAN_HARD) store_wb(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx);
                 }
             }
         }
