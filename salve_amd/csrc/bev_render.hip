@@ -101,6 +101,21 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
     // where the densify kernel finds the colour of point index i of this render: colour_src[rid] + 3 i
     if (blockIdx.x == 0 && threadIdx.x == 0) colour_src[rid] = rgb + ((size_t)h.pano_idx * c.pano_h + c.crop_rows) * c.pano_w * 3;
     const int p0 = (blockIdx.x * SCATTER_THREADS + threadIdx.x) * PTS_PER_THREAD;  // first point (cropped raster)
+    {   // Dead rows: z = d * zdir(v) with d >= 0 has the sign of zdir(v), so above the horizon no point can be floor and below
+        // it none can be ceiling -- half of the panorama's rows for either surface.  If every row this workgroup touches
+        // is dead for the render's z range, it has nothing to do (uniform exit, before any barrier).
+        const int pb = blockIdx.x * SCATTER_THREADS * PTS_PER_THREAD;
+        const int v_first = pb / c.pano_w + c.crop_rows;
+        const int v_last = min(pb + SCATTER_THREADS * PTS_PER_THREAD - 1, c.npts - 1) / c.pano_w + c.crop_rows;
+        const double* zd_ = sphere + c.pano_h;
+        const double zlo_ = c.zlo[h.surface], zhi_ = c.zhi[h.surface];
+        bool dead = dbg_xy == nullptr;
+        for (int v = v_first; v <= v_last && dead; v++) {
+            const double zv = zd_[v];
+            dead = zv > 0.0 ? zhi_ < 0.0 : (zv < 0.0 ? zlo_ >= 0.0 : !(zlo_ < 0.0 && zhi_ >= 0.0));
+        }
+        if (dead) return;
+    }
     __shared__ int block_acc[5];   // [0] points inside the window, [1..4] bounding box maxima
     if (pass == 0) {               // (uniform)
         if (threadIdx.x < 5) block_acc[threadIdx.x] = 0;
