@@ -93,7 +93,10 @@ struct SdTable {
 SD_FN int sdt_index(int ax, int ay) { return (ay + SDT_AMAX) * SDT_SIDE + (ax + SDT_AMAX); }
 
 SD_FN bool sd_occupied(const SdGrid& g, int x, int y) {
-    return x >= 0 && x < g.W && y >= 0 && y < g.H && ((g.occ[y * g.wpr + (x >> 5)] >> (x & 31)) & 1u);
+    // branch-free: an out-of-image probe reads word 0 and is masked (a guarded load costs an exec-mask round trip per probe)
+    const bool in = (unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H;
+    const int xi = in ? x : 0, yi = in ? y : 0;
+    return in & (bool)((g.occ[yi * g.wpr + (xi >> 5)] >> (xi & 31)) & 1u);
 }
 
 SD_FN int32_t sd_orient(int ax, int ay, int bx, int by, int cx, int cy) {

@@ -29,7 +29,10 @@ SD_FN uint32_t sdl_row32(const SdGrid& g, int y, int x0) {
 }
 
 SD_FN bool sdl_bit(const SdGrid& g, int x, int y) {
-    return x >= 0 && x < g.W && y >= 0 && y < g.H && ((g.occ[y * g.wpr + (x >> 5)] >> (x & 31)) & 1u);
+    // branch-free: an out-of-image probe reads word 0 and is masked (a guarded load costs an exec-mask round trip per probe)
+    const bool in = (unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H;
+    const int xi = in ? x : 0, yi = in ? y : 0;
+    return in & (bool)((g.occ[yi * g.wpr + (xi >> 5)] >> (xi & 31)) & 1u);
 }
 
 // Sites that need no walk at all.  If (x+1, y), (x-1, y) and the three pixels above, (x-1 .. x+1, y+1), are all sites, then
