@@ -353,6 +353,19 @@ struct RasterEmit {
 template <class T>
 __device__ __forceinline__ void store_wb(T* p, T v) { *p = v; }
 
+// Hard-site list: two words per entry, the site (y << 16 | x) and the state its lean walk was in when it gave up
+// (sd_star_resume: a + 128 in two bytes, n0 + 1 in two bits each, bit 20 counter-clockwise, bit 21 half walk), or
+// HARD_FRESH if there is nothing to take over.  A list that overflows (every second pixel a hard site) is a failed render.
+constexpr uint32_t HARD_FRESH = 1u << 22;
+__device__ __forceinline__ void push_hard(uint32_t* list, int* counter, int cap, uint32_t site, uint32_t state, int32_t* status) {
+    const int k = atomicAdd(counter, 1);
+    if (k < cap) {
+        *reinterpret_cast<uint2*>(list + 2 * k) = make_uint2(site, state);
+    } else if (status) {
+        atomicOr(status, SALVE_STATUS_WALK_FAILED);
+    }
+}
+
 // Emit functor of the local star walk: owned triangles go to a per-render queue (8 bytes each: the site, and the two
 // other vertices relative to it) and are rasterised afterwards by all lanes at once.
 //
@@ -676,6 +689,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
         SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13], (H <= 1024 && W <= 1024 && !(c.dbg_flags & 256)) ? tri_cache : nullptr};
         RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (c.dbg_flags & 2) != 0};
         QueueEmit qemit = {triq, &scal[8], (H * W) / 3, raster, &scal[15], &scal[16]};
+        const int hard_cap = (H * W) >> 1;   // entries of two words: the site, and where its lean walk stood
         SdLean st;
         bool active = false, exhausted = false;
         int iters = 0;
@@ -693,7 +707,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                         const uint32_t s = __hip_atomic_load(sitelist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (dbg_stats) { atomicAdd(&scal[9], 1); atomicAdd(&scal[10], (int)(s & 0xFFFFu) + (int)(s >> 16)); }
                         if (sdl_lean_begin(st, g, (int)(s & 0xFFFFu), (int)(s >> 16)) == SDL_LEAN_CONTINUE) active = true;
-                        else store_wb(hardlist + atomicAdd(&scal[7], 1), s);
+                        else push_hard(hardlist, &scal[7], hard_cap, s, HARD_FRESH, status);
                     }
                 }
             } else if (busy == 0ull) {
@@ -708,7 +722,10 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                     {
                         dbg_mask[((size_t)rid * H + st.sy) * W + st.sx] = (uint8_t)((r == SDL_LEAN_HARD ? 200 : 100) + min(st.deg, 50));
                     }
-                    if (r == SDL_LEAN_HARD) store_wb(hardlist + atomicAdd(&scal[7], 1), ((uint32_t)st.sy << 16) | (uint32_t)st.sx);
+                    if (r == SDL_LEAN_HARD)   // the general walk takes over at the edge this walk could not answer
+                        push_hard(hardlist, &scal[7], hard_cap, ((uint32_t)st.sy << 16) | (uint32_t)st.sx,
+                                  (uint32_t)((st.ax + 128) & 0xFF) | ((uint32_t)((st.ay + 128) & 0xFF) << 8) | ((uint32_t)(st.n0x + 1) << 16) |
+                                      ((uint32_t)(st.n0y + 1) << 18) | (st.dir > 0 ? 1u << 20 : 0u) | (st.half ? 1u << 21 : 0u), status);
                 }
             }
         }
@@ -720,7 +737,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
 #if defined(SALVE_PROFILE_WALK)
         SD_PHASE(1, t_phase);
 #endif
-        const int nhard = scal[7];
+        const int nhard = min(scal[7], hard_cap);
         const int qcap = (H * W) / 3;
         const int nq = min(scal[8], qcap), nmid = min(scal[15], qcap), ncen = min(scal[16], qcap);
         int err = 0;
@@ -749,8 +766,12 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                 i0 = __shfl(i0, gw.gbase);
                 if (i0 >= nh) break;
                 for (int i = i0; i < min(i0 + HARD_RUN, nh); i++) {
-                    const uint32_t s = __hip_atomic_load(hardlist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (sd_star(gw, (int)(s & 0xFFFFu), (int)(s >> 16), rw) < 0) err = 1;
+                    const uint32_t s = __hip_atomic_load(hardlist + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t w = __hip_atomic_load(hardlist + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int hx = (int)(s & 0xFFFFu), hy = (int)(s >> 16);
+                    const int r = sd_walk(gw, hx, hy, (w & HARD_FRESH) != 0, (int)(w & 0xFF) - 128, (int)((w >> 8) & 0xFF) - 128, (w >> 20) & 1u ? 1 : -1,
+                                          ((w >> 21) & 1u) != 0, (int)((w >> 16) & 3u) - 1, (int)((w >> 18) & 3u) - 1, rw);
+                    if (r < 0) err = 1;
                 }
             }
         }

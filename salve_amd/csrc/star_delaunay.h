@@ -565,52 +565,65 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
 // Walk the Delaunay star of site s and hand every triangle whose raster-first vertex is s to `emit`
 // (so each triangle of the triangulation is emitted exactly once over all sites), counter-clockwise.
 // Returns the number of wrap steps, or -1 if the safety bound was hit.
+//
+// Only triangles whose other two vertices FOLLOW s in raster order are emitted, i.e. neighbours at angles [0, pi)
+// counter-clockwise from +x.  Three modes, ONE loop (and one inlined copy of sd_apex and of the emit functor):
+//   HALF  the pixel to the right is a site -- the first of those neighbours, adjacent pixels always being Delaunay
+//         neighbours: walk counter-clockwise from it and stop at the first neighbour that precedes s, or at the hull;
+//   CCW   otherwise: counter-clockwise from some neighbour n0 (the nearest site) until the star closes at n0; if the hull
+//         comes first, s is a hull vertex and the fan is finished  CW  (clockwise) from n0 to the hull on the other side.
+// `fresh` = false takes the walk up where a lean walk (star_local.h) gave up: at the edge s -> s + (rax, ray) it could not
+// answer, in its direction, with its first neighbour n0 = s + (rn0x, rn0y) or as a half walk; what that walk emitted before
+// is not emitted again.
+enum { SD_MODE_HALF = 0, SD_MODE_CCW = 1, SD_MODE_CW = 2 };
 template <class Emit>
-SD_FN int sd_star(const SdGrid& g, int sx, int sy, Emit& emit) {
+SD_FN int sd_walk(const SdGrid& g, int sx, int sy, bool fresh, int rax, int ray, int rdir, bool rhalf, int rn0x, int rn0y, Emit& emit) {
     int steps = 0;
-    // Only triangles whose other two vertices FOLLOW s in raster order are emitted here, i.e. neighbours at angles
-    // [0, pi) counter-clockwise from +x.  If the pixel to the right is a site, it is the first of them (adjacent pixels
-    // are always Delaunay neighbours): walk counter-clockwise from it and stop at the first neighbour that precedes s,
-    // or at the hull.
-    if (sx + 1 < g.W && ((g.occ[sy * g.wpr + ((sx + 1) >> 5)] >> ((sx + 1) & 31)) & 1u)) {
-        int ax = sx + 1, ay = sy;
-        for (;;) {
-            int px, py;
-            if (!sd_apex(g, sx, sy, ax, ay, +1, &px, &py)) break;
-            if (!sd_before(sx, sy, px, py)) break;
-            { long long lap_e = SD_NOW(); emit(sx, sy, ax, ay, px, py); SD_LAP(e1_total, lap_e); }
-            if (++steps > SD_MAX_DEGREE) return -1;
-            ax = px;
-            ay = py;
-        }
-        return steps + 1;
+    int mode, ax, ay, n0x, n0y;
+    if (!fresh) {
+        mode = rhalf ? SD_MODE_HALF : (rdir > 0 ? SD_MODE_CCW : SD_MODE_CW);
+        ax = sx + rax; ay = sy + ray; n0x = sx + rn0x; n0y = sy + rn0y;
+    } else if (sx + 1 < g.W && ((g.occ[sy * g.wpr + ((sx + 1) >> 5)] >> ((sx + 1) & 31)) & 1u)) {
+        mode = SD_MODE_HALF;
+        ax = n0x = sx + 1; ay = n0y = sy;
+    } else {
+        long long lap_n = SD_NOW();
+        if (!sd_nearest(g, sx, sy, &n0x, &n0y)) return 0;
+        SD_LAP(nearest, lap_n);
+        mode = SD_MODE_CCW;
+        ax = n0x; ay = n0y;
     }
-    int n0x, n0y;
-    long long lap_n = SD_NOW();
-    if (!sd_nearest(g, sx, sy, &n0x, &n0y)) return 0;
-    SD_LAP(nearest, lap_n);
-    int ax = n0x, ay = n0y;
-    bool closed = false;
-    for (;;) {  // counter-clockwise from the nearest neighbour
+    const bool half = mode == SD_MODE_HALF;
+    for (;;) {
         int px, py;
-        if (!sd_apex(g, sx, sy, ax, ay, +1, &px, &py)) break;
-        if (sd_before(sx, sy, ax, ay) && sd_before(sx, sy, px, py)) { long long lap_e = SD_NOW(); emit(sx, sy, ax, ay, px, py); SD_LAP(e1_total, lap_e); }
+        if (!sd_apex(g, sx, sy, ax, ay, mode == SD_MODE_CW ? -1 : +1, &px, &py)) {
+            if (mode != SD_MODE_CCW) break;
+            mode = SD_MODE_CW;  // hull vertex: back to the first neighbour, the other way round
+            ax = n0x;
+            ay = n0y;
+            continue;
+        }
+        if (half && !sd_before(sx, sy, px, py)) break;
+        if (half || (sd_before(sx, sy, ax, ay) && sd_before(sx, sy, px, py))) {
+            const bool cw = mode == SD_MODE_CW;  // (counter-clockwise vertex order either way)
+            long long lap_e = SD_NOW();
+            emit(sx, sy, cw ? px : ax, cw ? py : ay, cw ? ax : px, cw ? ay : py);
+            SD_LAP(e1_total, lap_e);
+        }
         if (++steps > SD_MAX_DEGREE) return -1;
         ax = px;
         ay = py;
-        if (ax == n0x && ay == n0y) { closed = true; break; }
+        if (mode == SD_MODE_CCW && ax == n0x && ay == n0y) break;  // closed
     }
-    if (!closed) {  // s is a hull vertex: finish the fan clockwise from the nearest neighbour
-        ax = n0x;
-        ay = n0y;
-        for (;;) {
-            int px, py;
-            if (!sd_apex(g, sx, sy, ax, ay, -1, &px, &py)) break;
-            if (sd_before(sx, sy, ax, ay) && sd_before(sx, sy, px, py)) { long long lap_e = SD_NOW(); emit(sx, sy, px, py, ax, ay); SD_LAP(e1_total, lap_e); }
-            if (++steps > SD_MAX_DEGREE) return -1;
-            ax = px;
-            ay = py;
-        }
-    }
-    return steps;
+    return half ? steps + 1 : steps;
+}
+
+template <class Emit>
+SD_FN int sd_star(const SdGrid& g, int sx, int sy, Emit& emit) {
+    return sd_walk(g, sx, sy, true, 0, 0, 1, false, 0, 0, emit);
+}
+
+template <class Emit>
+SD_FN int sd_star_resume(const SdGrid& g, int sx, int sy, int rax, int ray, int dir, bool half, int rn0x, int rn0y, Emit& emit) {
+    return sd_walk(g, sx, sy, false, rax, ray, dir, half, rn0x, rn0y, emit);
 }

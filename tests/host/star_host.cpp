@@ -99,8 +99,14 @@ extern "C" int star_host_triangulate_local(const int* xs, const int* ys, int n, 
         if (r == SDL_LEAN_DONE) {
             out.insert(out.end(), mine.begin(), mine.end());
         } else {
-            hard++;   // the kernel rasterises what the lean walk had emitted, and then the general walk's triangles again
-            if (sd_star(g, xs[i], ys[i], c) < 0) return -1;
+            hard++;   // as in the kernel: what the lean walk emitted stays, the general walk takes over at the edge it gave up on
+            out.insert(out.end(), mine.begin(), mine.end());
+            const bool fresh = ls.n0x == SDL_NONE || g.tab == nullptr;   // gave up in sdl_lean_begin: nothing to take over
+            if (fresh) {
+                if (sd_star(g, xs[i], ys[i], c) < 0) return -1;
+            } else if (sd_star_resume(g, xs[i], ys[i], ls.ax, ls.ay, ls.dir, ls.half, ls.n0x, ls.n0y, c) < 0) {
+                return -1;
+            }
         }
     }
     if (stats) { stats[0] = iters; stats[1] = hard; stats[2] = maxit; }
