@@ -363,9 +363,13 @@ struct BottleneckArgs {
 
 constexpr int BN_THREADS = 512;  // 8 waves: two workgroups per CU give 4 waves per SIMD to hide the many short phases
 
-template <int MID, int TH>
+// PROJ: the first block of layer 1 -- its input has MID channels (not 4 MID) and its shortcut is a 1x1 projection, which rides
+//       in GEMM 3 as MID more k: Y = relu([t2 | X] . [Wc | Ws]^T + (bc + bs)), the weight rows K-concatenated as the
+//       three-kernel path stores them (conv1x1_with_shortcut), 64 output channels at a time.
+template <int MID, int TH, bool PROJ = false>
 __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArgs p) {
     constexpr int C4 = 4 * MID;
+    constexpr int CIN = PROJ ? MID : C4;   // channels of the block's input
     constexpr int HC = 18, HALO = (TH + 2) * HC;
     constexpr int M1 = (HALO + 63) / 64 * 64;   // GEMM-1 rows (halo pixels, zero padded): 192 (TH 8) / 128 (TH 4)
     constexpr int MT1 = M1 / 64;                // GEMM 1: 16-row tiles per wave (4 wave rows x 2 wave columns)
@@ -386,7 +390,9 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     constexpr int T1_E = M1 * MID, T2_E = MO * MID;
     constexpr int BSB_E = STAGE_TILES * MID * 64;
     constexpr int BSC_E = 128 * MID, CS_E = MO * LDC;
-    constexpr int EA = 2 * ST1_E, EB = T1_E + 2 * BSB_E, EC = T2_E + BSC_E + CS_E;
+    constexpr int LDC_P = 64 + 8;                                           // PROJ: 64 output channels per chunk
+    constexpr int EC_P = T2_E + MO * 64 + 64 * (MID + CIN) + MO * LDC_P;    // PROJ: t2 | X centre tile | weight chunk | staging
+    constexpr int EA = 2 * ST1_E, EB = T1_E + 2 * BSB_E, EC = PROJ ? EC_P : T2_E + BSC_E + CS_E;
     constexpr int SMEM_E = EA > EB ? (EA > EC ? EA : EC) : (EB > EC ? EB : EC);
     __shared__ __attribute__((aligned(1024))) uint16_t smem[SMEM_E];
     uint16_t* T1 = smem;
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     const int ty = t % p.tiles_y;
     const int b = t / p.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * 16;
-    const uint16_t* ximg = p.x + (long long)b * p.H * p.W * C4;
+    const uint16_t* ximg = p.x + (long long)b * p.H * p.W * CIN;
     const int frag_row = lane & 15, frag_q = lane >> 4;
     const int row_base = tid >> 3;
     const int chunk = (tid & 7) ^ ((row_base >> 1) & 7);   // source-side swizzle, as in conv_igemm_kernel
@@ -430,9 +436,9 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             const int h = row_base + 64 * i;
             const int hy = oy0 - 1 + h / HC, hx = ox0 - 1 + h % HC;
             const bool ok = h < HALO && hy >= 0 && hy < p.H && hx >= 0 && hx < p.W;
-            rowp[i] = ok ? ximg + ((long long)hy * p.W + hx) * C4 + chunk * 8 : nullptr;
+            rowp[i] = ok ? ximg + ((long long)hy * p.W + hx) * CIN + chunk * 8 : nullptr;
         }
-        const uint16_t* wrow = p.wa + (long long)row_base * C4 + chunk * 8;
+        const uint16_t* wrow = p.wa + (long long)row_base * CIN + chunk * 8;
         constexpr int A_LOADS = M1 / 64 + MID / 64;
 #define ISSUE_A(KT)                                                                                                    \
     {                                                                                                                  \
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             __builtin_amdgcn_global_load_lds((global_cptr)src, (lds_ptr)(As_ + (wave * 8 + 64 * i) * 64), 16, 0, 0);   \
         }                                                                                                              \
         _Pragma("unroll") for (int j = 0; j < MID / 64; j++)                                                           \
-            __builtin_amdgcn_global_load_lds((global_cptr)(wrow + (long long)j * 64 * C4 + (KT) * 64),                 \
+            __builtin_amdgcn_global_load_lds((global_cptr)(wrow + (long long)j * 64 * CIN + (KT) * 64),                \
                                              (lds_ptr)(As_ + M1 * 64 + (wave * 8 + 64 * j) * 64), 16, 0, 0);           \
     }
         f32x4 acc[MT1][NT1];
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         for (int i = 0; i < MT1; i++)
 #pragma unroll
             for (int j = 0; j < NT1; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int NK1 = C4 / 64;
+        constexpr int NK1 = CIN / 64;
         ISSUE_A(0);
         for (int kt = 0; kt < NK1; kt++) {
             // the next tile goes into the other buffer (last read one iteration ago, behind a barrier) and stays in
@@ -573,6 +579,85 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     }
 #undef ISSUE_WB
 
+    // ------------------------------------------------------------------ GEMM 3 (PROJ): Y = relu([t2 | X] . [Wc | Ws]^T + b)
+    if constexpr (PROJ) {
+        static_assert(!PROJ || MID == 64, "the projection variant is written for 64 mid channels");
+        constexpr int KP = MID + CIN;               // 128: k-tile 0 = t2, k-tile 1 = the block's input at the output pixels
+        uint16_t* Xc = smem + T2_E;                 // [MO][64], staged like a GEMM-1 tile (chunk q of row r at q ^ ((r >> 1) & 7))
+        uint16_t* Wp = Xc + MO * 64;                // weight chunk: two tiles of 64 rows x 64 k
+        uint16_t* Cp = Wp + 64 * KP;                // output staging [MO][LDC_P]
+        constexpr int CH_PER_ROW = 64 / 8;
+        constexpr int C_ITERS = (MO * CH_PER_ROW) / BN_THREADS;
+#pragma unroll
+        for (int i = 0; i < MO / 64; i++) {         // X centre tile (L2: GEMM 1 has just read it), lands with the first weights
+            const int r = row_base + 64 * i;
+            const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+            const uint16_t* src = ox < p.W ? ximg + ((long long)oy * p.W + ox) * CIN + chunk * 8 : p.zeros;
+            __builtin_amdgcn_global_load_lds((global_cptr)src, (lds_ptr)(Xc + (wave * 8 + 64 * i) * 64), 16, 0, 0);
+        }
+        for (int nc = 0; nc < C4 / 64; nc++) {
+#pragma unroll
+            for (int q = 0; q < KP / 64; q++)
+                __builtin_amdgcn_global_load_lds((global_cptr)(p.wc + (long long)(nc * 64 + row_base) * KP + q * 64 + chunk * 8),
+                                                 (lds_ptr)(Wp + q * 64 * 64 + (wave * 8) * 64), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // (first chunk: also orders the t2 stores)
+            f32x4 acc[RT][2];
+#pragma unroll
+            for (int i = 0; i < RT; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KP / 64; q++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    act8 af[RT], bfr[2];
+                    const uint16_t* A = q == 0 ? T2 : Xc;
+#pragma unroll
+                    for (int i = 0; i < RT; i++) {
+                        const int m = (wr * RT + i) * 16 + frag_row;
+                        af[i] = *reinterpret_cast<const act8*>(A + m * 64 + (((ks * 4 + frag_q) ^ ((m >> 1) & 7)) << 3));
+                    }
+                    const int slot = ((ks * 4 + frag_q) ^ ((frag_row >> 1) & 7)) * 8;
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        bfr[j] = *reinterpret_cast<const act8*>(Wp + q * 64 * 64 + ((wc * 2 + j) * 16 + frag_row) * 64 + slot);
+#pragma unroll
+                    for (int i = 0; i < RT; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int ncol = (wc * 2 + j) * 16 + 4 * frag_q;
+                const float4 bias = *reinterpret_cast<const float4*>(p.bc + nc * 64 + ncol);
+#pragma unroll
+                for (int i = 0; i < RT; i++) {
+                    const int m = (wr * RT + i) * 16 + frag_row;
+                    const float v0 = fmaxf(acc[i][j][0] + bias.x, 0.f), v1 = fmaxf(acc[i][j][1] + bias.y, 0.f);
+                    const float v2 = fmaxf(acc[i][j][2] + bias.z, 0.f), v3 = fmaxf(acc[i][j][3] + bias.w, 0.f);
+                    track4(amax, v0, v1, v2, v3);
+                    uint2 o;
+                    o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
+                    o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
+                    *reinterpret_cast<uint2*>(Cp + m * LDC_P + ncol) = o;
+                }
+            }
+            __syncthreads();
+            uint16_t* yimg = p.y + (long long)b * p.H * p.W * C4;
+#pragma unroll
+            for (int it = 0; it < C_ITERS; it++) {
+                const int id = tid + it * BN_THREADS;
+                const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
+                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+                if (ox < p.W)
+                    *reinterpret_cast<uint4*>(yimg + ((long long)oy * p.W + ox) * C4 + nc * 64 + ch * 8) =
+                        *reinterpret_cast<const uint4*>(Cp + m * LDC_P + ch * 8);
+            }
+            __syncthreads();  // staging and weight chunk are reused by the next chunk
+        }
+    } else
     // ------------------------------------------------------------------ GEMM 3: Y = relu(t2 . Wc^T + bc + X)
     {
         constexpr int CH_PER_ROW = 128 / 8;
@@ -781,7 +866,14 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
                                 a.Hi == c.Ho && a.Wi == c.Wo && b.Hi == a.Hi && b.Ho == a.Hi;
             // measured at batch 512: the 64-channel blocks (56 x 56) gain 15 % fused; the 128-channel blocks (28 x 28, 4 x 16
             // tiles) come out even, so they stay on the three-kernel path
-            if (!shapes || mid != 64 || a.Hi % 8 != 0) continue;
+            // ... or the first block of layer 1: input of `mid` channels, the projection shortcut in the last convolution's k
+            const bool proj = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.relu && a.res_buf == SALVE_NO_BUF && a.in2_buf == SALVE_NO_BUF &&
+                              a.Cin == mid && b.KH == 3 && b.KW == 3 && b.stride == 1 && b.pad == 1 && b.relu && b.res_buf == SALVE_NO_BUF &&
+                              b.in2_buf == SALVE_NO_BUF && b.Cin == mid && b.Cout == mid && b.in_buf == a.out_buf && c.KH == 1 && c.KW == 1 && c.stride == 1 &&
+                              c.pad == 0 && c.relu && c.res_buf == SALVE_NO_BUF && c.Cin == mid && c.Cout == 4 * mid && c.in_buf == b.out_buf &&
+                              c.in2_buf == a.in_buf && c.Cin2 == mid && c.stride2 == 1 && c.out_buf != a.in_buf && a.in_buf >= 0 && a.Hi == c.Ho &&
+                              a.Wi == c.Wo && b.Hi == a.Hi && b.Ho == a.Hi && c.Hi2 == a.Hi && c.Wi2 == a.Wi && !getenv("SALVE_RESNET_NO_PROJ_FUSE");
+            if (!(shapes || proj) || mid != 64 || a.Hi % 8 != 0) continue;
             // the two intermediate tensors are not produced by the fused kernel: nobody may read them afterwards
             bool dead = true;
             for (int which = 0; which < 2 && dead; which++) {
@@ -792,7 +884,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
                     if (o.out_buf == id) break;
                 }
             }
-            if (dead) { h->fused[i] = 1; i += 2; }
+            if (dead) { h->fused[i] = shapes ? 1 : 2; i += 2; }
         }
     }
     if (hipMalloc(&h->d_weights, weights_bytes) != hipSuccess || hipMalloc(&h->d_params, params_bytes) != hipSuccess ||
@@ -877,7 +969,8 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.tiles_y = o.Hi / (narrow ? 8 : 4);
             const long long grid = (long long)batch * a.tiles_x * a.tiles_y;
             if (grid > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
-            if (narrow) hipLaunchKernelGGL((bottleneck_kernel<64, 8>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
+            if (h->fused[oi] == 2) hipLaunchKernelGGL((bottleneck_kernel<64, 8, true>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
+            else if (narrow) hipLaunchKernelGGL((bottleneck_kernel<64, 8>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
             else hipLaunchKernelGGL((bottleneck_kernel<128, 4>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
             SALVE_HIP_CHECK(hipGetLastError());
             oi += 2;
