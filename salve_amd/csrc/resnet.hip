@@ -255,6 +255,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
 }
 
 #include "conv_wide.h"
+#include "conv8.h"
 #include "stem_pool.h"
 
 // 3x3 / stride 2 / pad 1 max-pool on NHWC fp16, 8 channels (16 bytes) per thread.
@@ -756,6 +757,7 @@ struct ResnetHandle {
     int num_layers = 0, in_channels = 0, ncls = 0;
     std::vector<int> fused;  // per op: 1 = this op and the next two form a bottleneck block run by bottleneck_kernel
     std::vector<int> wide;   // per op: 0 = conv_igemm_kernel, else a conv_wide_kernel configuration (WIDE_*)
+    bool wide_auto = false;  // the 8-phase kernel only for launches that fill the chip at least twice over (256 x 256 tiles)
     std::vector<int> stem;   // per op: 1 = this 7x7 / 2 convolution and the max-pool behind it run as stem_pool_kernel
 };
 
@@ -764,7 +766,7 @@ struct ResnetHandle {
 // per shape on MI355X ("wide tiles"): none beats the 128 x 128 kernel at four workgroups per CU by more
 // than a few per cent on any ResNet shape, so the default is OFF -- they stay selectable because the measurements and the
 // ablations that explain them are part of the design record.
-enum { WIDE_OFF = 0, WIDE_256_K64_S2 = 4, WIDE_128_K64_S1 = 5, WIDE_PC_128 = 6 };
+enum { WIDE_OFF = 0, WIDE_256_K64_S2 = 4, WIDE_128_K64_S1 = 5, WIDE_PC_128 = 6, WIDE_8PHASE = 7, WIDE_AUTO = 8 };
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -774,6 +776,11 @@ static int choose_wide(const salve_resnet_op_t& o, int force) {
     const int K = o.KH * o.KW * o.Cin + (o.in2_buf != SALVE_NO_BUF ? o.Cin2 : 0);
     if (!pointwise && (!is_pow2(o.Cin) || o.Cin < 64)) return WIDE_OFF;   // the stem keeps its table-driven gather
     if (K < 128 || K % 64 != 0) return WIDE_OFF;
+    if (force == WIDE_8PHASE || force == WIDE_AUTO) {
+        const bool fits = o.Cout % 256 == 0 && is_pow2(o.Cin) && o.Cin >= 64 && (o.in2_buf == SALVE_NO_BUF || o.Cin2 % 64 == 0);
+        // by default only where the convolution is compute-bound (measured per shape): k >= 512
+        return (fits && (force == WIDE_8PHASE || K >= 512)) ? WIDE_8PHASE : WIDE_OFF;
+    }
     if (force == WIDE_256_K64_S2) return o.Cout % 256 == 0 ? force : WIDE_OFF;
     return o.Cout % 128 == 0 ? force : WIDE_OFF;
 }
@@ -828,8 +835,11 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
     }
     h->wide.assign(h->ops.size(), 0);
     {
-        const char* e = getenv("SALVE_CONV_WIDE");   // unset: off; d, e, f: that alternative kernel wherever the shape allows it
-        const int mode = !e ? WIDE_OFF : (e[0] == 'd' ? WIDE_256_K64_S2 : (e[0] == 'e' ? WIDE_128_K64_S1 : (e[0] == 'f' ? WIDE_PC_128 : WIDE_OFF)));
+        // unset: the 8-phase kernel on the compute-bound shapes that fit it; 0: conv_igemm_kernel everywhere; 8: the 8-phase
+        // kernel wherever it fits; d, e, f: that alternative kernel of conv_wide.h wherever the shape allows it
+        const char* e = getenv("SALVE_CONV_WIDE");
+        const int mode = !e ? WIDE_AUTO : (e[0] == 'd' ? WIDE_256_K64_S2 : (e[0] == 'e' ? WIDE_128_K64_S1 : (e[0] == 'f' ? WIDE_PC_128 : (e[0] == '8' ? WIDE_8PHASE : WIDE_OFF))));
+        h->wide_auto = mode == WIDE_AUTO;
         for (size_t i = 0; i < h->ops.size(); i++) h->wide[i] = choose_wide(h->ops[i], mode);
     }
     h->stem.assign(h->ops.size(), 0);
@@ -999,9 +1009,14 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.KW = o.KW;
             a.cin_log2 = 0;
             while ((1 << a.cin_log2) < o.Cin) a.cin_log2++;
-            if (h->wide[oi] != WIDE_OFF) {
+            // (the 256 x 256 tiles of the 8-phase kernel are a quarter as many workgroups, one per CU: small launches stay on
+            //  conv_igemm_kernel -- the results are bit-identical either way)
+            // Measured on ResNet-50 (tools/bench_resnet.py): +1 % for the whole forward at batch 4096, -1 % at 2048 and below
+            // (one workgroup per CU: a launch of fewer than six rounds loses more in its last round than the kernel gains).
+            const bool few_tiles = h->wide[oi] == WIDE_8PHASE && h->wide_auto && ((M + 255) / 256) * (long long)(o.Cout / 256) < 1536;
+            if (h->wide[oi] != WIDE_OFF && !few_tiles) {
                 const int cfg = h->wide[oi];
-                const int bn = cfg == WIDE_256_K64_S2 ? 256 : 128;
+                const int bn = (cfg == WIDE_256_K64_S2 || cfg == WIDE_8PHASE) ? 256 : 128;
                 a.m_tiles = (int)((M + WIDE_BM - 1) / WIDE_BM);
                 a.n_tiles = o.Cout / bn;
                 const unsigned grid = (unsigned)(((a.m_tiles + 7) / 8) * 8 * a.n_tiles);
@@ -1012,7 +1027,11 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
         else if (pw) hipLaunchKernelGGL((conv_wide_kernel<BN_, KS_, NS_, true, false>), dim3(grid), dim3(WIDE_THREADS), 0, s, a);   \
         else hipLaunchKernelGGL((conv_wide_kernel<BN_, KS_, NS_, false, false>), dim3(grid), dim3(WIDE_THREADS), 0, s, a);          \
     }
-                if (cfg == WIDE_PC_128) {
+                if (cfg == WIDE_8PHASE) {
+                    if (src2) hipLaunchKernelGGL((conv8_kernel<true, true>), dim3(grid), dim3(C8_THREADS), 0, s, a);
+                    else if (pw) hipLaunchKernelGGL((conv8_kernel<true, false>), dim3(grid), dim3(C8_THREADS), 0, s, a);
+                    else hipLaunchKernelGGL((conv8_kernel<false, false>), dim3(grid), dim3(C8_THREADS), 0, s, a);
+                } else if (cfg == WIDE_PC_128) {
                     if (src2) hipLaunchKernelGGL((conv_pc_kernel<true, true>), dim3(grid), dim3(PC_THREADS), 0, s, a);
                     else if (pw) hipLaunchKernelGGL((conv_pc_kernel<true, false>), dim3(grid), dim3(PC_THREADS), 0, s, a);
                     else hipLaunchKernelGGL((conv_pc_kernel<false, false>), dim3(grid), dim3(PC_THREADS), 0, s, a);

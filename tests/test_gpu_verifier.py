@@ -241,7 +241,7 @@ def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool(monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("cfg", ["d", "e", "f"])
+@pytest.mark.parametrize("cfg", ["d", "e", "f", "8"])
 def test_alternative_convolution_kernels_are_bit_identical(monkeypatch, cfg):
     """SALVE_CONV_WIDE = d | e | f routes the convolutions through the wide-tile / split-role kernels of conv_wide.h where the
     shape allows it (read when the handle is created).  Same k order and fp32 accumulation as conv_igemm_kernel: the logits
