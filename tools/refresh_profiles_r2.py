@@ -26,7 +26,7 @@ o1, rows1 = stats("prof1", ["# rocprofv3 --kernel-trace --stats -- python3 bench
 n_launch = 3  # warm-up + 2 steps
 d = [r for r in rows1 if "bev_densify" in r["Name"]][0]
 sc = [r for r in rows1 if "bev_scatter_kernel" in r["Name"]][0]
-ver = sum(int(r["TotalDurationNs"]) for r in rows1 if any(k in r["Name"] for k in ("conv_igemm", "bottleneck", "stem_pool", "maxpool", "avgpool"))) / 1e6 / n_launch
+ver = sum(int(r["TotalDurationNs"]) for r in rows1 if any(k in r["Name"] for k in ("conv_igemm", "conv8_kernel", "conv_wide", "conv_pc", "bottleneck", "stem_pool", "maxpool", "avgpool"))) / 1e6 / n_launch
 o1 += ["", f"bev_densify_kernel: {d['Calls']} launches = {n_launch} of 4096 renders + 1 of 64 (identity renders): {(int(d['TotalDurationNs']) / 1e6 - 0.8) / n_launch:.2f} ms per 4096 renders;",
        f"bev_scatter_kernel: {sc['Calls']} launches (two passes each): {int(sc['TotalDurationNs']) / 1e6 / (n_launch + 64 / 4096):.2f} ms per 4096 renders;",
        f"verifier kernels: {ver:.2f} ms per 4096 samples = {4096 * 8.41 / ver:.0f} TFLOP/s = {4096 * 8.41 / ver / 25:.1f} % of the 2.5 PFLOP/s dense fp16 peak.",
@@ -44,7 +44,7 @@ def counters(d):
     for r in csv.DictReader(open(f)):
         e = disp.setdefault(int(r["Dispatch_Id"]), {"name": short(r["Kernel_Name"]), "start": int(r["Start_Timestamp"]), "end": int(r["End_Timestamp"])})
         e[r["Counter_Name"]] = float(r["Counter_Value"])
-    ks = [v for v in disp.values() if any(k in v["name"] for k in ("conv_igemm", "bottleneck", "stem_pool", "maxpool", "avgpool"))]
+    ks = [v for v in disp.values() if any(k in v["name"] for k in ("conv_igemm", "conv8_kernel", "conv_wide", "conv_pc", "bottleneck", "stem_pool", "maxpool", "avgpool"))]
     return ks[-(len(ks) // 3):]
 a, b, c = counters("sq1"), counters("sq2"), counters("sq3")
 assert len(a) == len(b) == len(c)
