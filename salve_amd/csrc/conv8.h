@@ -180,6 +180,8 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
     }
 #if defined(C8_NO_STAGE)
 #define C8_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#elif defined(C8_NO_VMWAIT)   // development: fills issued but never waited for (timing only, wrong results)
+#define C8_VMWAIT() asm volatile("s_waitcnt vmcnt(62)" ::: "memory")
 #else
 #define C8_VMWAIT() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #endif
@@ -304,3 +306,13 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
             *reinterpret_cast<uint4*>(p.out + (long long)m * p.Cout + n0 + ch * 8) = *reinterpret_cast<const uint4*>(Cs + r * LDC + ch * 8);
     }
 }
+
+// A variant that was built and dropped (conv8b): the WEIGHT fragments read straight from global memory into registers -- a
+// lane's fragment is 16 contiguous bytes of one weight row -- which takes the B half-tiles out of the LDS traffic (160 KB
+// instead of 256 KB per k-tile) and would, by the ablations above, be worth up to a third.  It cannot be scheduled with counted
+// waits: LDS-DMA operations and ordinary vector loads share the vmcnt counter but do NOT complete in order with respect to
+// each other, so "all but the last N" does not say WHICH operations have landed (with hand-counted waits the kernel computed
+// garbage, mostly in the lagging wave group; hipcc knows -- it puts s_waitcnt vmcnt(0) in front of the first use of an
+// ordinarily loaded register while LDS-DMA is outstanding, and with those drains the kernel is correct but no faster than
+// the one-stage kernels: a drain waits out the latency of whatever was issued last).  Staging A through registers as well
+// (all loads of one kind) does not fit the 256 VGPRs next to 128 accumulators.

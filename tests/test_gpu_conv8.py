@@ -25,7 +25,7 @@ SHAPES = [
 ]
 
 
-def _handles(lib, monkeypatch, shape, seed):
+def _handles(lib, monkeypatch, shape, seed, mode8):
     name, cin, cout, k, stride, pad, hw, res, src2 = shape
     g = torch.Generator().manual_seed(seed)
     bld = hip_resnet._Builder()
@@ -42,7 +42,7 @@ def _handles(lib, monkeypatch, shape, seed):
     pr = np.concatenate(bld.params).astype(np.float32)
     kt = np.concatenate(bld.ktab).astype(np.int32)
     out = []
-    for mode in ("0", "8"):
+    for mode in ("0", mode8):
         monkeypatch.setenv("SALVE_CONV_WIDE", mode)   # read when the handle is created
         h = lib.salve_resnet_create(0, cin, ops.ctypes.data_as(ctypes.c_void_p), 1, wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
                                     pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size)
@@ -51,12 +51,13 @@ def _handles(lib, monkeypatch, shape, seed):
     return out
 
 
+@pytest.mark.parametrize("mode8", ["8"], ids=["conv8"])
 @pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
-def test_eight_phase_kernel_is_bit_identical_and_stays_so(monkeypatch, shape):
+def test_eight_phase_kernel_is_bit_identical_and_stays_so(monkeypatch, shape, mode8):
     lib = _lib.load()
     name, cin, cout, k, stride, pad, hw, res, src2 = shape
     ho = (hw + 2 * pad - k) // stride + 1
-    h_ref, h_c8 = _handles(lib, monkeypatch, shape, seed=3)
+    h_ref, h_c8 = _handles(lib, monkeypatch, shape, seed=3, mode8=mode8)
     try:
         for B in (3, 41, 150):    # M = B ho^2: tiles cut by the end of M, one workgroup, several rounds
             out_elems = ho * ho * cout
