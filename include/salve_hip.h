@@ -34,8 +34,8 @@ typedef enum {
     SALVE_ERR_WORKSPACE = -4
 } salve_status_t;
 
-#define SALVE_HIP_ABI_VERSION 3  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter,
-                                     salve_bev_workspace_init */
+#define SALVE_HIP_ABI_VERSION 4  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter,
+                                     salve_bev_workspace_init; 4: salve_bev_tile_pairs */
 
 /* Device status word: an optional device int32 the caller zeroes once and passes to the launches below.  Kernels OR bits
  * into it when something went wrong that an int return value cannot report (the launch is asynchronous); the caller
@@ -204,6 +204,19 @@ typedef struct {
 int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs, int32_t n_jobs,
                     const int32_t* coef_y, const int32_t* coef_x, int32_t resize, int32_t crop, const float* lut,
                     void* out, int32_t out_format, int32_t out_c, void* stream);
+
+/* The two tiles of an early-fusion pair in ONE pass (the fused render -> verify driver's form of salve_bev_tiles, fp16 NHWC
+ * only): pair k takes its first image from bev_a + jobs_a[k].bev_offset and its second from bev_b + jobs_b[k].bev_offset,
+ * both go to sample jobs_a[k].slot ( == jobs_b[k].slot), channels jobs_a[k].chan .. + 2 and jobs_b[k].chan .. + 2, which
+ * must be the two halves of one group of six channels (min(chan) a multiple of 6, |chan_a - chan_b| == 3: the x1 | x2 of a
+ * surface, salve/models/early_fusion.py:52-60 -- either order: salve/dataset/zind_data.py:110).  A thread computes both
+ * pixels and writes the six channels (and, for the last group of a sample whose out_c leaves padding channels, the zero
+ * padding too) with whole-pixel stores, where two salve_bev_tiles calls write three 2-byte channels each.  Same arithmetic
+ * as salve_bev_tiles: bit-identical tiles.  (int return: SALVE_ERR_BAD_ARG on null pointers / bad sizes; the pairing rule
+ * is the caller's to keep.) */
+int salve_bev_tile_pairs(const uint32_t* bev_a, const uint32_t* bev_b, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs_a,
+                         const salve_tile_job_t* jobs_b, int32_t n_pairs, const int32_t* coef_y, const int32_t* coef_x, int32_t resize,
+                         int32_t crop, const float* lut, void* out, int32_t out_c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Verifier: early-fusion ResNet forward pass (fp16 MFMA, fp32 accumulation).

@@ -894,6 +894,59 @@ __global__ __launch_bounds__(256) void bev_tile_kernel(const uint32_t* __restric
     }
 }
 
+// One tile pixel of image `img`: cv2 INTER_LINEAR on uint8 with 11-bit taps, then the normalisation LUT (bev_tile_kernel's arithmetic).
+__device__ __forceinline__ void tile_pixel(const uint32_t* __restrict__ img, int W, const int4 cy, const int4 cx, const float* __restrict__ lut, float v[3]) {
+    const uint32_t p00 = img[(size_t)cy.x * W + cx.x], p01 = img[(size_t)cy.x * W + cx.y];
+    const uint32_t p10 = img[(size_t)cy.y * W + cx.x], p11 = img[(size_t)cy.y * W + cx.y];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const int a = (p00 >> (8 * ch)) & 255, b = (p01 >> (8 * ch)) & 255;
+        const int cc = (p10 >> (8 * ch)) & 255, d = (p11 >> (8 * ch)) & 255;
+        const int S0 = a * cx.z + b * cx.w;  // horizontal pass, x2048
+        const int S1 = cc * cx.z + d * cx.w;
+        int r = (((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2;
+        r = min(max(r, 0), 255);
+        v[ch] = lut[ch * 256 + r];
+    }
+}
+
+// Both tiles of an early-fusion pair per thread, six channels (plus the sample's zero padding behind its last group) in
+// whole-pixel stores: see salve_bev_tile_pairs in salve_hip.h.
+__global__ __launch_bounds__(256) void bev_tile_pair_kernel(const uint32_t* __restrict__ bev_a, const uint32_t* __restrict__ bev_b, int W,
+                                                            const salve_tile_job_t* __restrict__ jobs_a, const salve_tile_job_t* __restrict__ jobs_b,
+                                                            const int32_t* __restrict__ coef_y, const int32_t* __restrict__ coef_x, int resize,
+                                                            int crop, const float* __restrict__ lut, uint16_t* __restrict__ out, int out_c) {
+    const salve_tile_job_t ja = jobs_a[blockIdx.y], jb = jobs_b[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= crop * crop) return;
+    const int i = idx / crop, j = idx % crop;
+    const int off = (resize - crop) / 2;
+    const int4 cy = reinterpret_cast<const int4*>(coef_y)[i + off];
+    const int4 cx = reinterpret_cast<const int4*>(coef_x)[j + off];
+    float va[3], vb[3];
+    tile_pixel(bev_a + ja.bev_offset, W, cy, cx, lut, va);
+    tile_pixel(bev_b + jb.bev_offset, W, cy, cx, lut, vb);
+    const bool a_first = ja.chan < jb.chan;
+    const int c0 = a_first ? ja.chan : jb.chan;   // first of the group's six channels (a multiple of 6)
+    uint32_t w[3];                                // the six halves, two per word
+    {
+        const float* lo = a_first ? va : vb;
+        const float* hi = a_first ? vb : va;
+        w[0] = (uint32_t)f32_to_f16(lo[0]) | ((uint32_t)f32_to_f16(lo[1]) << 16);
+        w[1] = (uint32_t)f32_to_f16(lo[2]) | ((uint32_t)f32_to_f16(hi[0]) << 16);
+        w[2] = (uint32_t)f32_to_f16(hi[1]) | ((uint32_t)f32_to_f16(hi[2]) << 16);
+    }
+    uint16_t* px = out + ((size_t)ja.slot * crop * crop + idx) * out_c;
+    if (out_c == 8) {   // one surface: the whole 16-byte pixel, padding channels 6 and 7 included
+        *reinterpret_cast<uint4*>(px) = make_uint4(w[0], w[1], w[2], 0u);
+    } else {
+        uint32_t* o = reinterpret_cast<uint32_t*>(px + c0);   // c0 is even: 4-byte aligned
+        o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+        if (c0 + 12 > out_c)   // the sample's last group: zero the padding channels behind it
+            for (int c = c0 + 6; c < out_c; c += 2) *reinterpret_cast<uint32_t*>(px + c) = 0u;
+    }
+}
+
 __global__ __launch_bounds__(256) void bev_export_kernel(const uint32_t* __restrict__ bev, size_t npx,
                                                          uint8_t* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1305,6 +1358,23 @@ int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const sal
     dim3 g((crop * crop + 255) / 256, n_jobs);
     hipLaunchKernelGGL(bev_tile_kernel, g, dim3(256), 0, (hipStream_t)stream, bev, bev_w, jobs, coef_y, coef_x, resize, crop,
                        lut, out, out_format, out_c);
+    SALVE_HIP_CHECK(hipGetLastError());
+    return SALVE_OK;
+}
+
+int salve_bev_tile_pairs(const uint32_t* bev_a, const uint32_t* bev_b, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs_a,
+                         const salve_tile_job_t* jobs_b, int32_t n_pairs, const int32_t* coef_y, const int32_t* coef_x, int32_t resize,
+                         int32_t crop, const float* lut, void* out, int32_t out_c, void* stream) {
+    if (n_pairs == 0) return SALVE_OK;
+    if (!bev_a || !bev_b || !jobs_a || !jobs_b || !coef_y || !coef_x || !lut || !out || n_pairs < 0 || bev_h <= 0 || bev_w <= 0) {
+        salve_fail("salve_bev_tile_pairs: null pointer or bad size");
+        return SALVE_ERR_BAD_ARG;
+    }
+    if (crop <= 0 || resize < crop || out_c < 6 || out_c % 2 != 0) { salve_fail("salve_bev_tile_pairs: need 0 < crop <= resize, even out_c >= 6"); return SALVE_ERR_BAD_ARG; }
+    if (n_pairs > 65535) { salve_fail("at most 65535 tile pairs per call"); return SALVE_ERR_BAD_ARG; }
+    dim3 g((crop * crop + 255) / 256, n_pairs);
+    hipLaunchKernelGGL(bev_tile_pair_kernel, g, dim3(256), 0, (hipStream_t)stream, bev_a, bev_b, bev_w, jobs_a, jobs_b, coef_y, coef_x,
+                       resize, crop, lut, reinterpret_cast<uint16_t*>(out), out_c);
     SALVE_HIP_CHECK(hipGetLastError());
     return SALVE_OK;
 }

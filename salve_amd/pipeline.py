@@ -176,8 +176,9 @@ class RenderVerifyPipeline:
         if e1 is not None:
             e1.record()
         with tracing.range("salve.tiles"):
-            self.ras.tiles(bev, prepared["jobs1"][lo * S * jb:], n * S, tiles, _lib.TILE_F16_NHWC, self.engine.in_channels)
-            self.ras.tiles(self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, tiles, _lib.TILE_F16_NHWC, self.engine.in_channels)
+            # (jobs1[k] / jobs2[k] are the two halves of one surface's six channels of one sample: prepare())
+            self.ras.tile_pairs(bev, prepared["jobs1"][lo * S * jb:], self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, tiles,
+                                self.engine.in_channels)
 
     def _verify_chunk(self, buf: int, n: int, out: torch.Tensor, vtimers=None) -> None:
         e0 = e1 = None

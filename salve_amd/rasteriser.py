@@ -246,3 +246,16 @@ class BevRasteriser:
             )
         _lib.check(st, "salve_bev_tiles")
         return out
+
+    def tile_pairs(self, bev_a: torch.Tensor, jobs_a: torch.Tensor, bev_b: torch.Tensor, jobs_b: torch.Tensor, n_pairs: int,
+                   out: torch.Tensor, out_c: int) -> torch.Tensor:
+        """Both tiles of every early-fusion pair in one pass (fp16 NHWC; include/salve_hip.h: salve_bev_tile_pairs)."""
+        Hb, Wb = self.bev_hw
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_tile_pairs(
+                ctypes.c_void_p(bev_a.data_ptr()), ctypes.c_void_p(bev_b.data_ptr()), Hb, Wb, ctypes.c_void_p(jobs_a.data_ptr()),
+                ctypes.c_void_p(jobs_b.data_ptr()), n_pairs, ctypes.c_void_p(self.coef_y.data_ptr()), ctypes.c_void_p(self.coef_x.data_ptr()),
+                self.resize, self.crop, ctypes.c_void_p(self.lut.data_ptr()), ctypes.c_void_p(out.data_ptr()), out_c, self._stream(),
+            )
+        _lib.check(st, "salve_bev_tile_pairs")
+        return out

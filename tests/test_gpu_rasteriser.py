@@ -127,6 +127,30 @@ def test_tiles_match_oracle(setup):
     assert not got_bf[6:].any()
 
 
+def test_tile_pairs_equal_two_tile_calls(setup):
+    """salve_bev_tile_pairs (both tiles of an early-fusion pair per thread, whole-pixel stores, padding zeroed) against two
+    salve_bev_tiles calls: bit for bit, for one surface (8 channels) and two (16), either channel order, a dirty buffer."""
+    ras, panos, d_rgb, d_depth, hyp = setup
+    h = pack_hypotheses([0, 1, 2, 3], [0, 0, 1, 1], hyp.R[:4], hyp.t[:4], [1, 0, 1, 0])
+    bev, _ = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), 4)
+    other = bev.flip(0).contiguous()     # a second image array (the pipeline's cached identity renders)
+    for out_c, groups in ((8, 1), (16, 2)):
+        for swap in (0, 1):
+            # two samples; sample s, group g: images (2 s + g) % 4 of `bev` and of `other`
+            ja = ras.upload_tile_jobs([(2 * s + g) % 4 for s in range(2) for g in range(groups)], [s for s in range(2) for g in range(groups)],
+                                      [6 * g + 3 * swap for s in range(2) for g in range(groups)])
+            jb = ras.upload_tile_jobs([(2 * s + g + 1) % 4 for s in range(2) for g in range(groups)], [s for s in range(2) for g in range(groups)],
+                                      [6 * g + 3 * (1 - swap) for s in range(2) for g in range(groups)])
+            ref = torch.zeros((2, 224, 224, out_c), dtype=torch.float16, device=ras.device)
+            ras.tiles(bev, ja, 2 * groups, ref, _lib.TILE_F16_NHWC, out_c)
+            ras.tiles(other, jb, 2 * groups, ref, _lib.TILE_F16_NHWC, out_c)
+            got = torch.full((2, 224, 224, out_c), 7.0, dtype=torch.float16, device=ras.device)   # dirty: the padding must be written
+            ras.tile_pairs(bev, ja, other, jb, 2 * groups, got, out_c)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (out_c, swap)
+            assert got[..., :6 * groups].abs().sum() > 0
+
+
 def test_degenerate_inputs(setup):
     """Empty window, < 4 sites: the reference returns None / zeros (bev_rendering_utils.py:279, interpolation_utils.py:39)."""
     ras, panos, d_rgb, d_depth, hyp = setup
