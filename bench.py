@@ -9,6 +9,10 @@ child process -- before anything touches the GPU -- and relays the child's JSON 
 A step = one pass of the fused render+verify path over the rank's shard of the hypothesis table
 (BASELINE.json configs[2]: 4096 hypotheses over 64 synthetic 1024x512 panoramas, rasteriser + ResNet-50 fp16,
 per GPU -> weak scaling).  Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+BASELINE.json configs[4] on one GPU (same JSON schema, `config.workload` names it):
+    python bench.py --pano-hw 1024x2048 --surfaces floor,ceiling --layers 152 --hyps 1024 --panos 16 --chunk 512
+`--force-dist` runs `init_process_group("nccl")` and the logits all-gather even with a single rank (RCCL on one GPU).
 """
 
 from __future__ import annotations
@@ -29,17 +33,30 @@ sys.path.insert(0, str(ROOT))
 import numpy as np
 import torch
 
-# algorithmic bytes of one render at 1024x512 -> 501x501
-PANO_H, PANO_W, CROP = 512, 1024, 80
-BYTES_PER_RENDER = (PANO_H - 2 * CROP) * PANO_W * (3 + 2) + 501 * 501 * 3  # RGB u8 + depth u16 read, BEV u8 written
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0    # same guide: measured float4 copy
 MFMA_PEAK_TFLOPS = 2500.0      # same guide: dense fp16 / bf16 MFMA peak
-GFLOP_PER_SAMPLE = {50: 8.410, 152: 23.259, 18: 3.6}  # SURVEY 8d (2 x MAC, 6 input channels); tests/test_oracle_structure.py pins them
-# HBM bytes per render of the WHOLE rasteriser (key-image clear + both scatter passes + densify) from the PMC counters
-# (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes): see RASTERISER_TRAFFIC_SOURCE.  The narrow (4 B / lane) loads are
-# uncalibrated for FETCH_SIZE, so the read side is a lower bound.
-RASTERISER_TRAFFIC_BYTES_PER_RENDER = 5.56e6
-RASTERISER_TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.md"
+# SURVEY 8d (2 x MAC, conv + fc), keyed by (layers, input channels of the early fusion); tests/test_oracle_structure.py pins them
+GFLOP_PER_SAMPLE = {(50, 6): 8.410, (50, 12): 8.882, (152, 6): 23.259, (152, 12): 23.731, (18, 6): 3.6}
+# Counted HBM traffic (PMC FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes at the benchmark's launch shape) is READ from the
+# file the profile refresh writes -- never a constant in this script; a workload the file does not cover reports null.
+TRAFFIC_FILE = ROOT / "profiles" / "traffic.json"
+
+
+def bytes_per_render(pano_h: int, pano_w: int) -> int:
+    """algorithmic bytes of one render -- RGB u8 + depth u16 of the un-cropped rows read, the 501 x 501
+    BEV u8 written (2.555 MB at 1024x512, 7.96 MB at 2048x1024)."""
+    crop = int(pano_h * (80 / 512))
+    return (pano_h - 2 * crop) * pano_w * (3 + 2) + 501 * 501 * 3
+
+
+def counted_traffic(key: str):
+    """(bytes per unit, source) of `key` from profiles/traffic.json, or (None, None)."""
+    try:
+        e = json.loads(TRAFFIC_FILE.read_text())[key]
+        return float(e["bytes_per_unit"]), e["source"]
+    except Exception:
+        return None, None
 
 
 def _cores() -> int:
@@ -88,7 +105,8 @@ def cpu_baseline():
     cores = _cores()
     n_hyp = 16
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(min(cores, n_hyp)) as pool:
+    # spawn, not fork: this process has initialised the GPU by the time the baseline runs
+    with mp.get_context("spawn").Pool(min(cores, n_hyp)) as pool:
         tiles = pool.map(_cpu_render_pair, list(range(n_hyp)))
     t_render = time.perf_counter() - t0
     # single-process per-render latency (SURVEY 8d i)
@@ -144,6 +162,9 @@ def main() -> None:
                     "1 % -- the kernels then share the CUs and each runs longer -- and blur the per-kernel times the rooflines are computed from);\n"
                     "2: rasteriser | verifier; 3: scatter | densify | verifier, the rasteriser of pass k + 1 under the verifier of pass k")
     ap.add_argument("--layers", type=int, default=50)
+    ap.add_argument("--pano-hw", default="512x1024", help="panorama HxW: 512x1024 (configs 1-4) | 1024x2048 (config 5)")
+    ap.add_argument("--surfaces", default="floor", help="floor | ceiling | floor,ceiling (config 5: 12-channel early fusion)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the logits all-gather even with one rank")
     ap.add_argument("--scene", default="box", help="synthetic scene: box (SURVEY 8d) | cluttered (occluding boxes + door opening)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -155,11 +176,20 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    pano_h, pano_w = (int(v) for v in args.pano_hw.lower().split("x"))
+    surfaces = [v.strip() for v in args.surfaces.split(",")]
+    modalities = [f"{v}_rgb_texture" for v in surfaces]
+    S = len(surfaces)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
 
+        if "MASTER_ADDR" not in os.environ:   # --force-dist without a launcher: a world of one on the loop-back interface
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from salve_amd import synthetic
@@ -167,10 +197,10 @@ def main() -> None:
     from salve_amd.pipeline import RenderVerifyPipeline, gather_logits
 
     torch.manual_seed(0)
-    model = EarlyFusionCEResnet(args.layers, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    model = EarlyFusionCEResnet(args.layers, False, 2, SimpleNamespace(modalities=modalities)).eval()
     synthetic.trained_looking_batchnorm(model)  # random-init weights of the named architecture; seeded trained-looking statistics
-    pipe = RenderVerifyPipeline(model, dev, pano_hw=(PANO_H, PANO_W), chunk=args.chunk, overlap=(args.streams > 1 and not args.no_overlap), streams=args.streams)
-    panos = [synthetic.make_pano(i, PANO_H, PANO_W, scene=args.scene) for i in range(args.panos)]
+    pipe = RenderVerifyPipeline(model, dev, pano_hw=(pano_h, pano_w), chunk=args.chunk, overlap=(args.streams > 1 and not args.no_overlap), streams=args.streams)
+    panos = [synthetic.make_pano(i, pano_h, pano_w, scene=args.scene) for i in range(args.panos)]
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     # weak scaling: every rank scores its own block of `hyps` hypotheses out of a table of world * hyps
     n_total = args.hyps * world
@@ -180,23 +210,23 @@ def main() -> None:
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         pipe.score(prepared, out=logits)
-        gather_logits(logits, world, total=n_total)
+        gather_logits(logits, world, total=n_total, force=args.force_dist)
     ev, vev = [], []  # HIP events around every rasteriser stage / verifier forward of the timed region, on their own streams
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         pipe.score(prepared, out=logits, timers=ev, vtimers=vev)
-        allg = gather_logits(logits, world, total=n_total)
+        allg = gather_logits(logits, world, total=n_total, force=args.force_dist)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     pipe.check("bench.py")            # no star walk failed, no activation left the fp16 range
@@ -204,39 +234,53 @@ def main() -> None:
 
     if rank == 0:
         value = n_total * args.steps / dt
-        full_n = min(args.chunk, len(table))
-        mean_ms = lambda tag: float(np.mean([a.elapsed_time(b) for a, b, r, t in ev if t == tag and r == full_n]))
+        full_n = min(args.chunk, len(table))           # hypotheses per launch
+        renders = full_n * S                           # renders per rasteriser launch
+        bpr = bytes_per_render(pano_h, pano_w)
+        mean_ms = lambda tag: float(np.mean([a.elapsed_time(b) for a, b, r, t in ev if t == tag and r == renders]))
         scat_ms, dens_ms = mean_ms("scatter"), mean_ms("densify")
         ras_ms = scat_ms + dens_ms
-        achieved = full_n * BYTES_PER_RENDER / (ras_ms * 1e-3) / 1e9
+        achieved = renders * bpr / (ras_ms * 1e-3) / 1e9
         vfull = [(a.elapsed_time(b), r) for a, b, r in vev if r == full_n]
         ver_ms = float(np.mean([t for t, _ in vfull]))
-        tflops = full_n * GFLOP_PER_SAMPLE[args.layers] / ver_ms  # GFLOP / ms = TFLOP/s
+        gflop = GFLOP_PER_SAMPLE[(args.layers, 6 * S)]
+        tflops = full_n * gflop / ver_ms  # GFLOP / ms = TFLOP/s
+        shape = f"{pano_w}x{pano_h}/{'+'.join(surfaces)}/resnet{args.layers}/launch{full_n}"
+        ras_traffic, ras_src = counted_traffic(f"rasteriser/{pano_w}x{pano_h}/launch{renders}")
+        ver_traffic, ver_src = counted_traffic(f"verifier/resnet{args.layers}-{6 * S}ch/launch{full_n}")
+        ver_alg, _ = counted_traffic(f"verifier_algorithmic/resnet{args.layers}-{6 * S}ch")
+        config5 = (pano_h, pano_w, S, args.layers) == (1024, 2048, 2, 152)
         out = {
             "metric": "alignment hypotheses/sec (render+verify)", "value": round(value, 2), "unit": "hypotheses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": f"{args.hyps} hypotheses/GPU over {args.panos} synthetic 1024x512 panoramas ({args.scene} scene), floor surface, "
-                                   f"HIP BEV rasteriser + ResNet-{args.layers} (6-ch early fusion) fp16 MFMA verifier",
-                       "hypotheses_per_gpu": args.hyps, "panos": args.panos, "renders_per_hypothesis": 1,
-                       "cached_identity_renders": args.panos, "chunk": args.chunk, "hip_streams": 1 if args.no_overlap else args.streams,
-                       "parallelism": f"hypothesis-shard x{world}"},
-            # the rasteriser as a whole (key-image clear + two scatter passes + densify): SURVEY 8d's 2.555 MB per render x the
-            # renders of one launch / the summed average durations of those launches (HIP events on the launching streams)
-            "roofline": {"kernel": "rasteriser: key-image clear + bev_scatter_kernel x2 + bev_densify_kernel", "bound": "hbm",
+            "config": {"workload": f"{'BASELINE config 5: ' if config5 else ''}{args.hyps} hypotheses/GPU over {args.panos} synthetic {pano_w}x{pano_h} panoramas "
+                                   f"({args.scene} scene), {' + '.join(surfaces)} surface{'s' if S > 1 else ''}, HIP BEV rasteriser + ResNet-{args.layers} "
+                                   f"({6 * S}-ch early fusion) fp16 MFMA verifier",
+                       "shape": shape, "hypotheses_per_gpu": args.hyps, "panos": args.panos, "renders_per_hypothesis": S,
+                       "cached_identity_renders": args.panos * S, "chunk": args.chunk, "hip_streams": 1 if args.no_overlap else args.streams,
+                       "parallelism": f"hypothesis-shard x{world}", "rccl": bool(use_dist)},
+            # the rasteriser as a whole (two scatter passes + densify): SURVEY 8d's bytes per render x the renders of one launch /
+            # the summed average durations of those launches (HIP events on the launching streams)
+            "roofline": {"kernel": "rasteriser: bev_scatter_kernel x2 + bev_densify_kernel", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": int(RASTERISER_TRAFFIC_BYTES_PER_RENDER * full_n), "traffic_source": RASTERISER_TRAFFIC_SOURCE,
+                         "traffic": None if ras_traffic is None else int(ras_traffic * renders), "traffic_source": ras_src,
                          "launch_ms": round(ras_ms, 3), "scatter_ms": round(scat_ms, 3), "densify_ms": round(dens_ms, 3),
-                         "launches_timed": len(vfull), "renders_per_launch": full_n, "algorithmic_bytes_per_render": BYTES_PER_RENDER},
-            "roofline_verifier": {"kernel": "conv_igemm / bottleneck kernels of one ResNet forward", "bound": "mfma",
+                         "launches_timed": len(vfull), "renders_per_launch": renders, "algorithmic_bytes_per_render": bpr},
+            # the verifier against BOTH of its roofs: the dense fp16 MFMA peak (frac) and the HBM time of its activation traffic at
+            # the present fusion level (bound_hbm_ms = algorithmic activation + weight bytes / 6.3 TB/s achievable)
+            "roofline_verifier": {"kernel": "stem_pool / bottleneck / conv kernels of one ResNet forward", "bound": "mfma",
                                   "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(tflops / MFMA_PEAK_TFLOPS, 5), "launch_ms": round(ver_ms, 3),
-                                  "samples_per_launch": full_n, "gflop_per_sample": GFLOP_PER_SAMPLE[args.layers], "traffic": None},
+                                  "samples_per_launch": full_n, "gflop_per_sample": gflop,
+                                  "bound_mfma_ms": round(full_n * gflop / MFMA_PEAK_TFLOPS, 3),
+                                  "bound_hbm_ms": None if ver_alg is None else round(ver_alg * full_n / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3, 3),
+                                  "traffic": None if ver_traffic is None else int(ver_traffic * full_n), "traffic_source": ver_src},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -17,6 +17,7 @@ import os
 LIB_PATH = Path(os.environ.get("SALVE_HIP_LIB") or (Path(__file__).resolve().parent / "libsalve_hip.so"))
 
 SALVE_OK = 0
+EXPECTED_ABI = 4          # include/salve_hip.h: SALVE_HIP_ABI_VERSION
 TILE_F32_NCHW = 0
 TILE_F16_NHWC = 1
 
@@ -131,9 +132,12 @@ def load() -> ctypes.CDLL:
     lib.salve_resnet_forward.restype = ctypes.c_int
     lib.salve_resnet_num_layers.argtypes = [vp]
     lib.salve_resnet_num_layers.restype = ctypes.c_int
-    # development entry point (salve_amd/csrc/salve_debug.h), not part of the product ABI
-    lib.salve_debug_burn.argtypes = [i32, i32, i32, vp, vp]
-    lib.salve_debug_burn.restype = ctypes.c_int
+    # The bindings above are written for ONE ABI: an older or newer library (a stale git-ignored .so, a SALVE_HIP_LIB override
+    # built from another revision) would be called with shifted arguments -- device memory corruption instead of an error.
+    got = int(lib.salve_hip_version())
+    if got != EXPECTED_ABI:
+        raise SalveHipError(f"{LIB_PATH} reports ABI version {got}, these bindings are written for {EXPECTED_ABI}: rebuild it "
+                            "(python __graft_entry__.py --force)")
     _lib = lib
     return lib
 

@@ -43,14 +43,8 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
     constexpr int RING_E = 8 * C8_HALF_E, C_E = BM * LDC;
     __shared__ __attribute__((aligned(1024))) uint16_t smem[RING_E > C_E ? RING_E : C_E];
 
-    int m_tile, n_tile;
-    {   // XCD-aware: the n-tiles of one m-tile (same activation rows) share id % 8, i.e. one XCD's L2
-        const int per_group = 8 * p.n_tiles;
-        const int g = blockIdx.x / per_group, r = blockIdx.x % per_group;
-        m_tile = g * 8 + (r & 7);
-        n_tile = r >> 3;
-        if (m_tile >= p.m_tiles) return;
-    }
+    int m_tile, n_tile;   // XCD-aware (resnet.hip: xcd_tile)
+    if (!xcd_tile(blockIdx.x, p.m_tiles, p.n_tiles, p.xcd_contig, m_tile, n_tile)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int m0 = m_tile * BM, n0 = n_tile * BN;

@@ -62,13 +62,7 @@ void conv_wide_kernel(ConvArgs p) {
     __shared__ __attribute__((aligned(1024))) uint16_t smem[RING_E > C_E ? RING_E : C_E];
 
     int m_tile, n_tile;
-    {   // XCD-aware: the n-tiles of one m-tile (same activation rows) share id % 8, i.e. one XCD's L2
-        const int per_group = 8 * p.n_tiles;
-        const int g = blockIdx.x / per_group, r = blockIdx.x % per_group;
-        m_tile = g * 8 + (r & 7);
-        n_tile = r >> 3;
-        if (m_tile >= p.m_tiles) return;
-    }
+    if (!xcd_tile(blockIdx.x, p.m_tiles, p.n_tiles, p.xcd_contig, m_tile, n_tile)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
@@ -318,13 +312,7 @@ __global__ __launch_bounds__(PC_THREADS, 4) void conv_pc_kernel(ConvArgs p) {
     __shared__ __attribute__((aligned(1024))) uint16_t smem[RING_E > C_E ? RING_E : C_E];
 
     int m_tile, n_tile;
-    {
-        const int per_group = 8 * p.n_tiles;
-        const int g = blockIdx.x / per_group, r = blockIdx.x % per_group;
-        m_tile = g * 8 + (r & 7);
-        n_tile = r >> 3;
-        if (m_tile >= p.m_tiles) return;
-    }
+    if (!xcd_tile(blockIdx.x, p.m_tiles, p.n_tiles, p.xcd_contig, m_tile, n_tile)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int nst = p.K / KS;

@@ -43,24 +43,59 @@ struct ConvArgs {
     int Hi2, Wi2, Cin2, stride2, nkt1;
     int32_t* status;        // device status word (salve_hip.h) or nullptr
     int KW, cin_log2;       // conv_wide_kernel: padded kernel width, log2(Cin) (Cin is a power of two there)
+    int xcd_contig;         // workgroup -> tile mapping: 1 = every XCD owns a contiguous range of m-tiles (xcd_tile below)
 };
+
+// Workgroup -> tile, XCD-aware.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with an L2 of its own), so
+// XCD x runs ids x, x + 8, x + 16, ... in that order.  `contig`: XCD x owns the m-tiles [x * mper, (x + 1) * mper), walks them
+// in order and runs the n-tiles of one m-tile back to back -- the n-tiles share their activation rows through that L2, AND
+// consecutive m-tiles (the neighbouring image rows a 3x3 gather reads again) stay in the same L2.  Measured (round 3, PMC
+// FETCH_SIZE at batch 4096): with m-tiles dealt round-robin instead (m_tile % 8 = XCD, the round-1 mapping) the 3x3 kernels
+// fetched 1.8 - 2.1 x their input from HBM and the stride-2 3x3 of layer 2 ran AT the HBM roof (6.5 TB/s) on re-reads.
+// The grid is 8 * mper * n_tiles workgroups, mper = ceil(m_tiles / 8); workgroups beyond the last m-tile leave at once.
+__device__ __forceinline__ bool xcd_tile(int id, int m_tiles, int n_tiles, int contig, int& m_tile, int& n_tile) {
+    if (contig) {
+        const int mper = (m_tiles + 7) >> 3;
+        const int xcd = id & 7, s = id >> 3;
+        n_tile = s % n_tiles;
+        m_tile = xcd * mper + s / n_tiles;
+        return s / n_tiles < mper && m_tile < m_tiles;
+    }
+    const int per_group = 8 * n_tiles;
+    const int g = id / per_group, r = id % per_group;
+    m_tile = g * 8 + (r & 7);
+    n_tile = r >> 3;
+    return m_tile < m_tiles;
+}
+// The same for a one-dimensional list of `n` tiles (fused bottleneck blocks, stem strips): XCD x owns a contiguous range, so
+// the tiles of one image -- which share halo rows -- meet in one L2.  Bijective for every n (the guide's form).
+__device__ __forceinline__ int xcd_linear(int id, int n, int contig) {
+    if (!contig) return id;
+    const int q = n >> 3, r = n & 7, xcd = id & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
 
 // Activations and weights are IEEE half precision (fp16: 11 significand bits; the MFMA rate is that of bf16).  With bf16
 // storage (8 bits) the logits of the 152-layer network missed the 1e-3 parity bound; fp16 meets it with margin.  The
 // conversion saturates at the fp16 range instead of producing infinities.
 __device__ __forceinline__ float act_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
 __device__ __forceinline__ uint16_t f32_to_act(float f) {
-    f = fminf(fmaxf(f, -65504.f), 65504.f);  // (a NaN stays a NaN through the conversion below)
+    f = fminf(fmaxf(f, -65504.f), 65504.f);  // (v_max / v_min return the non-NaN operand: a NaN input comes out as -65504)
     return __builtin_bit_cast(uint16_t, (_Float16)f);
 }
 // Saturation must not pass silently: every epilogue folds the magnitudes it stores into `amax` (v_max3_f32 with |.|
 // source modifiers: half an instruction per value) and reports once per thread when the fp16 range was exceeded.
+// NaN: the hardware maxima used here and in the ReLUs return their non-NaN operand, so a NaN activation is turned into 0 by
+// the next ReLU instead of propagating to the logits as it does in torch -- and does NOT set the status bit.  A NaN can enter
+// only through the network input or the weights (fp16 products accumulated in fp32 do not overflow): the host refuses
+// non-finite weights when it packs them (hip_resnet.build_program), the rasteriser's tiles are finite by construction, and
+// a caller that hands its own tensors to EarlyFusionCEResnet.forward is told so there.
 __device__ __forceinline__ void track4(float& amax, float v0, float v1, float v2, float v3) {
     amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
     amax = fmaxf(amax, fmaxf(fabsf(v2), fabsf(v3)));
 }
 __device__ __forceinline__ void report_range(int32_t* status, float amax) {
-    if (status && !(amax <= 65504.f)) atomicOr(status, SALVE_STATUS_FP16_RANGE);  // (!(<=): a NaN reports too)
+    if (status && !(amax <= 65504.f)) atomicOr(status, SALVE_STATUS_FP16_RANGE);
 }
 
 typedef __attribute__((address_space(1))) const void* global_cptr;
@@ -86,16 +121,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     constexpr int C_ELEMS = BM * LDC;
     __shared__ __attribute__((aligned(1024))) uint16_t smem[STAGE_ELEMS > C_ELEMS ? STAGE_ELEMS : C_ELEMS];
 
-    // Workgroup -> tile, XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so
-    // the n-tiles of one m-tile (same activation rows) are given ids that share id % 8 and run close together in time.
     int m_tile, n_tile;
-    {
-        const int per_group = 8 * p.n_tiles;
-        const int g = blockIdx.x / per_group, r = blockIdx.x % per_group;
-        m_tile = g * 8 + (r & 7);
-        n_tile = r >> 3;
-        if (m_tile >= p.m_tiles) return;
-    }
+    if (!xcd_tile(blockIdx.x, p.m_tiles, p.n_tiles, p.xcd_contig, m_tile, n_tile)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases need no per-load readfirstlane
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
@@ -254,7 +281,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     }
 }
 
+#ifdef SALVE_BUILD_ABLATIONS   // the measured-and-rejected wide-tile kernels d / e / f: tools/build_ablations.sh only
 #include "conv_wide.h"
+#endif
 #include "conv8.h"
 #include "stem_pool.h"
 
@@ -360,6 +389,7 @@ struct BottleneckArgs {
     const uint16_t* zeros;
     int B, H, W, tiles_x, tiles_y;
     int32_t* status;
+    int xcd_contig;   // 1: every XCD owns a contiguous range of tiles (xcd_linear), so the tiles of one image share an L2
 };
 
 constexpr int BN_THREADS = 512;  // 8 waves: two workgroups per CU give 4 waves per SIMD to hide the many short phases
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases need no per-load readfirstlane
     const int wr = wave >> 1, wc = wave & 1;   // GEMM 2 / 3
     const int wm = wave & 3, wn = wave >> 2;   // GEMM 1
-    int t = blockIdx.x;
+    int t = xcd_linear(blockIdx.x, gridDim.x, p.xcd_contig);
     const int tx = t % p.tiles_x; t /= p.tiles_x;
     const int ty = t % p.tiles_y;
     const int b = t / p.tiles_y;
@@ -428,6 +458,22 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         }                                                                                                              \
     }
     constexpr int WB_LOADS = STAGE_TILES * (MID / 64);
+
+    // The residual of GEMM 3 is the block's own input at the output pixels -- a subset of the halo tile GEMM 1 streams through
+    // LDS.  Each thread copies the 8-byte pieces its GEMM-3 accumulators will need (pixel rows wr * RT + i, the 16 channels per
+    // accumulator tile of wave column wc: k-tile kt serves the waves with wc == (kt & 1), chunk nc = kt >> 1) out of the
+    // stage buffers into registers while the tile is there: 32 VGPRs instead of a second trip to memory for 64 KB per tile
+    // (round 3, PMC: the re-read came from beyond the L2 and was 30 % of the kernel's HBM traffic).
+    uint2 resid[PROJ ? 1 : C4 / 128][RT][4];
+    int res_off[RT];   // element offset of the pixel's row in a stage buffer, and its swizzle
+    int res_swz[RT];
+#pragma unroll
+    for (int i = 0; i < RT; i++) {
+        const int m = (wr * RT + i) * 16 + frag_row;
+        const int h = ((m >> 4) + 1) * HC + (m & 15) + 1;
+        res_off[i] = h * 64 + 4 * (frag_q & 1);
+        res_swz[i] = (h >> 1) & 7;
+    }
 
     // ------------------------------------------------------------------ GEMM 1: t1 = relu(Xhalo . Wa^T + ba)
     {
@@ -459,6 +505,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             for (int j = 0; j < NT1; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr int NK1 = CIN / 64;
         ISSUE_A(0);
+#pragma unroll
         for (int kt = 0; kt < NK1; kt++) {
             // the next tile goes into the other buffer (last read one iteration ago, behind a barrier) and stays in
             // flight under this tile's MFMAs: counted wait, raw barriers (a __syncthreads() would drain it)
@@ -471,6 +518,15 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             asm volatile("s_barrier" ::: "memory");
             const uint16_t* As = smem + (kt & 1) * ST1_E;
             const uint16_t* BsA = As + M1 * 64;
+            if constexpr (!PROJ) {
+                if (wc == (kt & 1)) {
+#pragma unroll
+                    for (int i = 0; i < RT; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            resid[kt >> 1][i][j] = *reinterpret_cast<const uint2*>(As + res_off[i] + (((2 * j + (frag_q >> 1)) ^ res_swz[i]) << 3));
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const int slot = ((ks * 4 + frag_q) ^ ((frag_row >> 1) & 7)) * 8;
@@ -663,6 +719,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     {
         constexpr int CH_PER_ROW = 128 / 8;
         constexpr int C_ITERS = (MO * CH_PER_ROW) / BN_THREADS;
+#pragma unroll
         for (int nc = 0; nc < C4 / 128; nc++) {
             // Wc chunk: 128 output channels x MID, as KT_MID tiles of 128 rows x 64
 #pragma unroll
@@ -671,16 +728,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 for (int j = 0; j < 2; j++)
                     __builtin_amdgcn_global_load_lds((global_cptr)(p.wc + (long long)(nc * 128 + row_base + 64 * j) * MID + q * 64 + chunk * 8),
                                                      (lds_ptr)(BsC + q * 128 * 64 + (wave * 8 + 64 * j) * 64), 16, 0, 0);
-            // residual tile (the block's own input at the output pixels) -> staging, 16-byte coalesced
-#pragma unroll
-            for (int it = 0; it < C_ITERS; it++) {
-                const int id = tid + it * BN_THREADS;
-                const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
-                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                uint4 v = uint4{0u, 0u, 0u, 0u};
-                if (ox < p.W) v = *reinterpret_cast<const uint4*>(ximg + ((long long)oy * p.W + ox) * C4 + nc * 128 + ch * 8);
-                *reinterpret_cast<uint4*>(Cs + m * LDC + ch * 8) = v;
-            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // (first chunk: also orders the t2 stores)
             f32x4 acc[RT][4];
@@ -717,7 +764,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 for (int i = 0; i < RT; i++) {
                     const int m = (wr * RT + i) * 16 + frag_row;
                     uint2* cell = reinterpret_cast<uint2*>(Cs + m * LDC + ncol);
-                    const uint2 r = *cell;
+                    const uint2 r = resid[nc][i][j];   // (a pixel beyond the image's right edge holds zeros: its halo row was the zero page)
                     const float v0 = fmaxf(acc[i][j][0] + bias.x + act_to_f32((uint16_t)(r.x & 0xFFFFu)), 0.f);
                     const float v1 = fmaxf(acc[i][j][1] + bias.y + act_to_f32((uint16_t)(r.x >> 16)), 0.f);
                     const float v2 = fmaxf(acc[i][j][2] + bias.z + act_to_f32((uint16_t)(r.y & 0xFFFFu)), 0.f);
@@ -759,13 +806,14 @@ struct ResnetHandle {
     std::vector<int> wide;   // per op: 0 = conv_igemm_kernel, else a conv_wide_kernel configuration (WIDE_*)
     bool wide_auto = false;  // the 8-phase kernel only for launches that fill the chip at least twice over (256 x 256 tiles)
     std::vector<int> stem;   // per op: 1 = this 7x7 / 2 convolution and the max-pool behind it run as stem_pool_kernel
+    int xcd_contig = 1;      // SALVE_XCD_CONTIG=0: the round-1 mapping (m-tiles dealt round-robin to the XCDs), for A/B runs
 };
 
-// Alternative convolution kernels (conv_wide.h), selected with SALVE_CONV_WIDE=d|e|f when a handle is created.  They are
-// bit-identical to conv_igemm_kernel (same k order, same fp32 accumulation; tests/test_gpu_verifier.py) and were measured
-// per shape on MI355X ("wide tiles"): none beats the 128 x 128 kernel at four workgroups per CU by more
-// than a few per cent on any ResNet shape, so the default is OFF -- they stay selectable because the measurements and the
-// ablations that explain them are part of the design record.
+// SALVE_CONV_WIDE (read when a handle is created): unset = the 8-phase 256 x 256 kernel (conv8.h) on the compute-bound shapes
+// that fit it, 0 = conv_igemm_kernel everywhere, 8 = the 8-phase kernel wherever it fits.  d | e | f select the wide-tile /
+// split-role kernels of conv_wide.h, which were measured per shape on MI355X and rejected: they exist
+// only in the ablation build (-DSALVE_BUILD_ABLATIONS, tools/build_ablations.sh) -- the product library treats them as 0.
+// All of them are bit-identical to conv_igemm_kernel (same k order, same fp32 accumulation).
 enum { WIDE_OFF = 0, WIDE_256_K64_S2 = 4, WIDE_128_K64_S1 = 5, WIDE_PC_128 = 6, WIDE_8PHASE = 7, WIDE_AUTO = 8 };
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -838,9 +886,17 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
         // unset: the 8-phase kernel on the compute-bound shapes that fit it; 0: conv_igemm_kernel everywhere; 8: the 8-phase
         // kernel wherever it fits; d, e, f: that alternative kernel of conv_wide.h wherever the shape allows it
         const char* e = getenv("SALVE_CONV_WIDE");
+#ifdef SALVE_BUILD_ABLATIONS
         const int mode = !e ? WIDE_AUTO : (e[0] == 'd' ? WIDE_256_K64_S2 : (e[0] == 'e' ? WIDE_128_K64_S1 : (e[0] == 'f' ? WIDE_PC_128 : (e[0] == '8' ? WIDE_8PHASE : WIDE_OFF))));
+#else
+        const int mode = !e ? WIDE_AUTO : (e[0] == '8' ? WIDE_8PHASE : WIDE_OFF);
+#endif
         h->wide_auto = mode == WIDE_AUTO;
         for (size_t i = 0; i < h->ops.size(); i++) h->wide[i] = choose_wide(h->ops[i], mode);
+    }
+    {
+        const char* e = getenv("SALVE_XCD_CONTIG");
+        h->xcd_contig = (e && atoi(e) == 0) ? 0 : 1;
     }
     h->stem.assign(h->ops.size(), 0);
     {
@@ -957,7 +1013,7 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.bias = h->d_params + o.b_off;
             a.y = buf(pool.out_buf);
             a.zeros = h->d_zeros;
-            a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status;
+            a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status; a.xcd_contig = h->xcd_contig;
             const long long grid = (long long)batch * ((o.Hi / 4) / STEM_R);
             if (grid > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
             hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)grid), dim3(STEM_THREADS), 0, s, a);
@@ -973,7 +1029,7 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.wa = h->d_weights + o.w_off; a.wb = h->d_weights + ob.w_off; a.wc = h->d_weights + oc.w_off;
             a.ba = h->d_params + o.b_off; a.bb = h->d_params + ob.b_off; a.bc = h->d_params + oc.b_off;
             a.zeros = h->d_zeros;
-            a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status;
+            a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status; a.xcd_contig = h->xcd_contig;
             a.tiles_x = (o.Wi + 15) / 16;
             const bool narrow = o.Cout == 64;  // 64 mid channels: 8 x 16 pixel tiles; 128: 4 x 16
             a.tiles_y = o.Hi / (narrow ? 8 : 4);
@@ -996,6 +1052,7 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.ktab = h->d_ktab + o.ktab_off;
             a.zeros = h->d_zeros;
             a.status = status;
+            a.xcd_contig = h->xcd_contig;
             a.B = batch; a.Hi = o.Hi; a.Wi = o.Wi; a.Cin = o.Cin; a.Ho = o.Ho; a.Wo = o.Wo; a.Cout = o.Cout;
             a.stride = o.stride; a.pad = o.pad; a.K = o.KH * o.KW * o.Cin; a.relu = o.relu;
             const bool src2 = o.in2_buf != SALVE_NO_BUF;
@@ -1017,27 +1074,32 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             if (h->wide[oi] != WIDE_OFF && !few_tiles) {
                 const int cfg = h->wide[oi];
                 const int bn = (cfg == WIDE_256_K64_S2 || cfg == WIDE_8PHASE) ? 256 : 128;
-                a.m_tiles = (int)((M + WIDE_BM - 1) / WIDE_BM);
+                a.m_tiles = (int)((M + C8_BM - 1) / C8_BM);
                 a.n_tiles = o.Cout / bn;
                 const unsigned grid = (unsigned)(((a.m_tiles + 7) / 8) * 8 * a.n_tiles);
                 const bool pw = o.KH == 1 && o.KW == 1 && o.stride == 1 && o.pad == 0;
+#ifdef SALVE_BUILD_ABLATIONS
 #define WIDE_LAUNCH(BN_, KS_, NS_)                                                                                                  \
     {                                                                                                                               \
         if (src2) hipLaunchKernelGGL((conv_wide_kernel<BN_, KS_, NS_, true, true>), dim3(grid), dim3(WIDE_THREADS), 0, s, a);       \
         else if (pw) hipLaunchKernelGGL((conv_wide_kernel<BN_, KS_, NS_, true, false>), dim3(grid), dim3(WIDE_THREADS), 0, s, a);   \
         else hipLaunchKernelGGL((conv_wide_kernel<BN_, KS_, NS_, false, false>), dim3(grid), dim3(WIDE_THREADS), 0, s, a);          \
     }
+#endif
                 if (cfg == WIDE_8PHASE) {
                     if (src2) hipLaunchKernelGGL((conv8_kernel<true, true>), dim3(grid), dim3(C8_THREADS), 0, s, a);
                     else if (pw) hipLaunchKernelGGL((conv8_kernel<true, false>), dim3(grid), dim3(C8_THREADS), 0, s, a);
                     else hipLaunchKernelGGL((conv8_kernel<false, false>), dim3(grid), dim3(C8_THREADS), 0, s, a);
-                } else if (cfg == WIDE_PC_128) {
+                }
+#ifdef SALVE_BUILD_ABLATIONS
+                else if (cfg == WIDE_PC_128) {
                     if (src2) hipLaunchKernelGGL((conv_pc_kernel<true, true>), dim3(grid), dim3(PC_THREADS), 0, s, a);
                     else if (pw) hipLaunchKernelGGL((conv_pc_kernel<true, false>), dim3(grid), dim3(PC_THREADS), 0, s, a);
                     else hipLaunchKernelGGL((conv_pc_kernel<false, false>), dim3(grid), dim3(PC_THREADS), 0, s, a);
                 } else if (cfg == WIDE_256_K64_S2) WIDE_LAUNCH(256, 64, 2)
                 else WIDE_LAUNCH(128, 64, 1)
 #undef WIDE_LAUNCH
+#endif
                 SALVE_HIP_CHECK(hipGetLastError());
                 continue;
             }

@@ -30,6 +30,7 @@ struct StemArgs {
     const uint16_t* zeros;
     int B, H, W;
     int32_t* status;
+    int xcd_contig;   // 1: every XCD owns a contiguous range of strips (resnet.hip: xcd_linear): neighbouring strips share 7 of their 23 input rows
 };
 
 __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) {
@@ -43,7 +44,8 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) 
 
     const int W = p.W, H = p.H, PC = W + 6, Wo = W >> 1, Ho = H >> 1, Wp = Wo >> 1, Hp = Ho >> 1;
     const int strips = Hp / R;
-    const int b = blockIdx.x / strips, s = blockIdx.x % strips;
+    const int blk = xcd_linear(blockIdx.x, gridDim.x, p.xcd_contig);
+    const int b = blk / strips, s = blk % strips;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frag_row = lane & 15, frag_q = lane >> 4;
     const int iy_base = 4 * R * s - 5;                         // input row of patch row 0

@@ -98,6 +98,10 @@ def run_test_epoch(args, serialization_save_dir: str, ckpt_fpath: str, model, da
         gt = torch.as_tensor(is_match).to(dev)
         probs, _ = train_utils.cross_entropy_forward(model, split, *xs, gt)
         y_hat = torch.argmax(probs, dim=1)
+        if dev.type == "cuda":   # the host reads the predictions next: saturated fp16 activations must not pass as logits
+            from salve_amd import status
+
+            status.check(dev, f"run_test_epoch, batch {i}")
         cls.update(y_hat.cpu().numpy(), gt.reshape(-1).cpu().numpy())
         pr.update(y_true=gt.reshape(-1).cpu().numpy(), y_hat=y_hat.cpu().numpy())
         if serialize_predictions:

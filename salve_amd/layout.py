@@ -25,6 +25,9 @@ WDO_COLOR_DICT_CV2 = {"windows": RED, "doors": GREEN, "openings": BLUE}   # bev_
 LayoutSpec = Tuple[np.ndarray, Sequence[Tuple[str, np.ndarray]]]
 
 
+MAX_LAYOUTS_PER_LAUNCH = 65535   # include/salve_hip.h: salve_layout_rasterise
+
+
 def world_to_pixels(bev_params: BEVParams, xy: np.ndarray) -> np.ndarray:
     """rasterize_polygon / rasterize_polyline :187-188, :214-215."""
     return np.round(bev_params.bevimg_Sim2_world.transform_from(np.asarray(xy, dtype=np.float64).reshape(-1, 2))).astype(np.int64)
@@ -70,10 +73,16 @@ def rasterise_layouts(specs: Sequence[LayoutSpec], device, bev_params: Optional[
     d_poly = torch.from_numpy(np.ascontiguousarray(poly_np)).to(device)
     d_seg = torch.from_numpy(np.ascontiguousarray(seg_np)).to(device)
     out = torch.empty((n, H, W), dtype=torch.int32, device=device)
+    rec_bytes = _lib.LAYOUT_DTYPE.itemsize
     with torch.cuda.device(device):
-        st = lib.salve_layout_rasterise(ctypes.c_void_p(d_rec.data_ptr()), n, ctypes.c_void_p(d_poly.data_ptr()), ctypes.c_void_p(d_seg.data_ptr()),
-                                        H, W, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
-    _lib.check(st, "salve_layout_rasterise")
+        # salve_layout_rasterise takes at most 65535 images per call (one grid dimension): a floor's hypotheses go in chunks;
+        # the records carry absolute offsets into the shared vertex / segment arrays, so a chunk is a slice of the record table
+        for lo in range(0, n, MAX_LAYOUTS_PER_LAUNCH):
+            m = min(MAX_LAYOUTS_PER_LAUNCH, n - lo)
+            st = lib.salve_layout_rasterise(ctypes.c_void_p(d_rec.data_ptr() + lo * rec_bytes), m, ctypes.c_void_p(d_poly.data_ptr()),
+                                            ctypes.c_void_p(d_seg.data_ptr()), H, W, ctypes.c_void_p(out[lo:].data_ptr()),
+                                            ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+            _lib.check(st, "salve_layout_rasterise")
     return out
 
 

@@ -64,7 +64,9 @@ class EarlyFusionCEResnet(nn.Module):
 
     def forward(self, x1: Tensor, x2: Tensor, x3: Optional[Tensor], x4: Optional[Tensor], x5: Optional[Tensor],
                 x6: Optional[Tensor]) -> torch.Tensor:
-        """Early fusion = concatenation along channels (early_fusion.py:55-65), then the ResNet."""
+        """Early fusion = concatenation along channels (early_fusion.py:55-65), then the ResNet.
+        Inputs must be finite: the HIP kernels' ReLUs turn a NaN activation into 0 instead of propagating it to the logits
+        as torch does (salve_amd/csrc/resnet.hip: track4).  Magnitudes beyond fp16 are reported through `check()`."""
         n = num_input_images(self.modalities)  # raises RuntimeError on unsupported sets, like the reference
         xs = [x1, x2, x3, x4, x5, x6][:n]
         if any(x is None for x in xs):
@@ -75,6 +77,14 @@ class EarlyFusionCEResnet(nn.Module):
             raise RuntimeError("the HIP verifier is inference-only: call model.eval() / use torch.no_grad()")
         eng = self.compiled(x1.device)
         return eng.forward_nhwc(nchw_to_input(xs, eng.in_channels))
+
+    def check(self, device=None, what: str = "EarlyFusionCEResnet.forward") -> None:
+        """The forward is asynchronous: an activation beyond the fp16 range is saturated AND reported in the device status word
+        (salve_hip.h).  Call this where the host reads the logits (it synchronises); it raises instead of letting the logits of
+        a different network through.  evaluate.run_test_epoch / run_fused_epoch and the pipeline do."""
+        from salve_amd import status
+
+        status.check(device if device is not None else torch.device("cuda", torch.cuda.current_device()), what)
 
     def forward_nhwc(self, x: Tensor) -> Tensor:
         """Fused-pipeline entry: fp16 [B,224,224,Cpad] tiles written by the rasteriser -> fp32 logits."""

@@ -160,6 +160,12 @@ def build_program(state_dict: Dict[str, torch.Tensor], num_layers: int, in_hw: T
     feat = sd["fc.weight"].shape[1]
     b.fc(sd["fc.weight"], sd["fc.bias"], x, H, W, feat)
     ops = np.array(b.ops, dtype=OP_DTYPE)
+    # the kernels' ReLUs and range tracking swallow NaNs (resnet.hip: track4): a non-finite weight -- a diverged checkpoint --
+    # would come out as finite, wrong logits; refuse it here, where torch would have propagated it to the output
+    for arr, what in ((np.concatenate(b.weights).astype(np.int16).view(np.float16), "convolution weights (after folding BatchNorm)"),
+                      (np.concatenate(b.params), "biases / fc parameters")):
+        if not np.isfinite(arr.astype(np.float32)).all():
+            raise ValueError(f"checkpoint has non-finite {what}, or values beyond the fp16 range")
     return ops, np.concatenate(b.weights).astype(np.int16), np.concatenate(b.params).astype(np.float32), \
         np.concatenate(b.ktab).astype(np.int32), cin_p
 

@@ -50,6 +50,9 @@ class RenderVerifyPipeline:
     def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: int = 512,
                  overlap: bool = True, streams: int = 3) -> None:
         self.device = torch.device(device)
+        # the status word is one per device: a bit an earlier, unchecked caller left behind must be reported as ITS failure,
+        # not raised later by this pipeline's check() under the wrong name
+        status.check(self.device, "a launch issued before this RenderVerifyPipeline was created")
         self.model = model
         self.surfaces = surfaces_for(model.modalities)
         self.engine = model.compiled(self.device)
@@ -255,13 +258,14 @@ class RenderVerifyPipeline:
         status.check(self.device, what)
 
 
-def gather_logits(local: torch.Tensor, world: int, total: Optional[int] = None) -> torch.Tensor:
+def gather_logits(local: torch.Tensor, world: int, total: Optional[int] = None, force: bool = False) -> torch.Tensor:
     """The path's only collective: one all-gather of the per-rank fp32 logits (mirrors DataParallel's gather of the model
     outputs, reference train_utils.py:214-215).  Shards of a contiguous block split differ by at most one row
     (HypothesisTable.shard_bounds), so every rank pads its block to ceil(total / world) rows for the single
     `all_gather_into_tensor` and the padding is dropped afterwards.  `total` = rows of the whole table (default: every
-    rank holds local.shape[0] rows)."""
-    if world == 1:
+    rank holds local.shape[0] rows).  `force`: run the collective even in a world of one (bench.py --force-dist: the RCCL
+    path on a single GPU)."""
+    if world == 1 and not force:
         return local
     import torch.distributed as dist
 

@@ -77,6 +77,7 @@ def render_building_floor_pairs(depth_save_root: str, bev_save_root: str, hypoth
             ras.render_counted(store.rgb, store.depth, ras.upload_hypotheses(h), len(part), bev, counts)
             out.append(ras.export_u8(bev).cpu().numpy())
             cnts.append(counts.cpu().numpy())
+            ras.check(f"render_building_floor_pairs({building_id}, {floor_id})")   # before any of these images is written to disk
         return np.concatenate(out), np.concatenate(cnts)
 
     eye, zero = np.eye(2, dtype=np.float32), np.zeros(2, dtype=np.float32)

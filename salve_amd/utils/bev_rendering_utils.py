@@ -69,7 +69,9 @@ def render_bev_image(bev_params: BEVParams, xyzrgb: np.ndarray, is_semantics: bo
     bev, n_in_window = ras.render_points(xyzrgb[:, :3], rgb_u8)
     if n_in_window == 0:
         return None
-    return ras.export_u8(bev)[0].cpu().numpy()
+    out = ras.export_u8(bev)[0].cpu().numpy()
+    ras.check("render_bev_image")   # device status word: a star walk that did not close must not produce a silent, incomplete image
+    return out
 
 
 def grayscale_to_color(gray_img: np.ndarray) -> np.ndarray:
@@ -147,6 +149,7 @@ def render_bev_pair(args, building_id: str, floor_id: str, i1: int, i2: int, i2T
     if int(counts.min().item()) == 0:
         return None, None
     out = ras.export_u8(bev).cpu().numpy()
+    ras.check("render_bev_pair")
     return out[0], out[1]
 
 

@@ -42,12 +42,11 @@ def interp_dense_grid_from_sparse(bev_img: np.ndarray, points: np.ndarray, rgb_v
     ras.cfg.out_flags = 3  # no flip, no mask: the plain interpolant
     xy = torch.from_numpy(np.ascontiguousarray(points[:, :2], dtype=np.int32)).to(dev)
     rgb = torch.from_numpy(np.ascontiguousarray(rgb_values).astype(np.uint8)).to(dev)
-    ws = ras._workspace(1)
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
-    st = ras.lib.salve_bev_keys_from_pixels(ctypes.byref(ras.cfg), p(xy), p(rgb), int(xy.shape[0]), p(ws), ws.numel(), ras._stream())
-    _lib.check(st, "salve_bev_keys_from_pixels")
+    ras.keys_from_pixels(xy, rgb)
     bev = ras.densify(1, torch.empty((1, grid_h, grid_w), dtype=torch.int32, device=dev))
-    bev_img[...] = ras.export_u8(bev)[0].cpu().numpy()
+    out = ras.export_u8(bev)[0].cpu().numpy()
+    ras.check("interp_dense_grid_from_sparse")   # a star walk that did not close = an incomplete interpolant: never silently
+    bev_img[...] = out
     return bev_img
 
 

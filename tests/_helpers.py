@@ -26,3 +26,18 @@ def oracle_floor_render(args):
     if r is None:
         return None, None
     return r["bev"], np.asarray(r["img_xy"]).astype(np.int16)
+
+
+def load_testhelp():
+    """tests/native/libsalve_testhelp.so (built by __graft_entry__.build()): synthetic load kernels for co-residency tests.
+    A test helper, not part of the product library."""
+    import ctypes
+    from pathlib import Path
+
+    path = Path(__file__).resolve().parent / "native" / "libsalve_testhelp.so"
+    if not path.exists():
+        raise RuntimeError(f"{path} is missing: run __graft_entry__.build()")
+    lib = ctypes.CDLL(str(path))
+    lib.salve_debug_burn.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.salve_debug_burn.restype = ctypes.c_int
+    return lib

@@ -1,11 +1,10 @@
-// debug_tools.hip -- development aids (not part of the hot path): synthetic load kernels used to study how the
-// rasteriser behaves next to other work on the same compute units.
+// testhelp.hip -- TEST helper library (tests/native/libsalve_testhelp.so, built by __graft_entry__.build()): synthetic load
+// kernels used to study how the rasteriser behaves next to other work on the same compute units.  Not part of the product:
+// libsalve_hip.so neither contains nor exports any of this.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/salve_hip.h"
-#include "salve_common.h"
-#include "salve_debug.h"
+#include "testhelp.h"
 
 namespace {
 typedef __attribute__((__ext_vector_type__(8))) __bf16 bf16x8;
@@ -44,6 +43,5 @@ __global__ __launch_bounds__(256) void burn_kernel(int iters, int mode, float* s
 
 extern "C" int salve_debug_burn(int32_t blocks, int32_t iters, int32_t mode, float* sink, void* stream) {
     hipLaunchKernelGGL(burn_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, mode, sink);
-    SALVE_HIP_CHECK(hipGetLastError());
-    return SALVE_OK;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }

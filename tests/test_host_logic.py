@@ -270,3 +270,42 @@ def test_cluttered_scene_is_a_box_room_with_occluders():
         assert z.min() >= synthetic.FLOOR_Z - 1e-3 and z.max() <= synthetic.CEILING_Z + 1e-3
     assert np.array_equal(synthetic.make_pano(2, 64, 128)[1], synthetic.make_box_room_depth_mm(2, 64, 128))
     assert np.array_equal(synthetic.make_pano(2, 64, 128, scene="cluttered")[0], synthetic.make_pano(2, 64, 128)[0])
+
+
+def test_bindings_refuse_a_library_of_another_abi(monkeypatch):
+    """_lib.load() compares salve_hip_version() with the ABI the ctypes signatures were written for: a stale git-ignored .so or a
+    SALVE_HIP_LIB override built from another revision would otherwise be called with shifted arguments."""
+    from salve_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "EXPECTED_ABI", _lib.EXPECTED_ABI + 1)
+    with pytest.raises(_lib.SalveHipError, match="ABI version"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load().salve_hip_version() == _lib.EXPECTED_ABI
+
+
+def test_the_product_library_exports_no_development_entry_points():
+    """salve_debug_burn lives in the TEST helper library (tests/native), not in libsalve_hip.so."""
+    import ctypes
+
+    from salve_amd import _lib
+
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    assert not hasattr(lib, "salve_debug_burn")
+    helper = ROOT / "tests" / "native" / "libsalve_testhelp.so"
+    assert helper.exists() and hasattr(ctypes.CDLL(str(helper)), "salve_debug_burn")
+
+
+def test_non_finite_weights_are_refused_when_the_program_is_packed():
+    """The HIP kernels' ReLUs swallow NaNs (resnet.hip: track4), torch propagates them: a diverged checkpoint must not come out
+    as finite logits -- hip_resnet.build_program raises instead."""
+    from salve_amd.models import hip_resnet
+
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["layout"])).eval()
+    sd = model.state_dict()
+    hip_resnet.build_program(sd, 18)
+    sd["resnet.layer3.0.conv1.weight"][3, 2, 1, 1] = float("nan")
+    with pytest.raises(ValueError, match="non-finite"):
+        hip_resnet.build_program(sd, 18)

@@ -70,10 +70,16 @@ def test_resnet_oracle_structure_matches_the_survey(num_layers, n_images, gmac, 
 
 
 def test_flop_constants_of_the_bench_line():
-    """bench.py prices the verifier at 2 x MAC of the convolutions + fc: 8.410 / 23.731 GFLOP per sample."""
-    for layers, n_images, gflop in ((50, 2, 8.410), (152, 4, 23.731)):
+    """bench.py prices the verifier at 2 x MAC of the convolutions + fc, keyed by (layers, input channels):
+    8.410 (ResNet-50, 6 ch), 8.882 (50, 12), 23.259 (152, 6), 23.731 (152, 12: BASELINE config 5) GFLOP per sample -- the
+    constants of bench.py itself are checked, and so are its algorithmic bytes per render (2.555 MB / 7.96 MB)."""
+    import bench
+
+    for layers, n_images in ((50, 2), (50, 4), (152, 2), (152, 4)):
         sd = EarlyFusionCEResnet(layers, False, 2, SimpleNamespace(modalities=MODS[n_images])).state_dict()
-        assert abs(2 * count_macs(sd, layers, n_images) / 1e9 - gflop) < 2e-3
+        assert abs(2 * count_macs(sd, layers, n_images) / 1e9 - bench.GFLOP_PER_SAMPLE[(layers, 3 * n_images)]) < 2e-3
+    assert bench.GFLOP_PER_SAMPLE[(50, 6)] == 8.410 and bench.GFLOP_PER_SAMPLE[(152, 12)] == 23.731
+    assert bench.bytes_per_render(512, 1024) == 2_555_243 and abs(bench.bytes_per_render(1024, 2048) / 1e6 - 7.96) < 0.01
 
 
 @pytest.fixture(scope="module")

@@ -4,6 +4,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np, torch
 from salve_amd import synthetic
 from salve_amd.rasteriser import BevRasteriser, pack_hypotheses
+sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
+from _helpers import load_testhelp
+helper = load_testhelp()   # the synthetic load kernels live in the test helper library, not in the product
 dev = torch.device("cuda:0")
 ras = BevRasteriser(dev)
 panos = [synthetic.make_pano(i) for i in range(4)]
@@ -112,7 +115,7 @@ if mode.startswith("burn") and mode[4:].isdigit():
     sink = torch.zeros(4, device=dev)
     for rep in range(6):
         for _ in range(6):
-            lib.salve_debug_burn(1024, 4000, bm, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+            helper.salve_debug_burn(1024, 4000, bm, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
         out, _ = ras.render(d_rgb, d_depth, hd, n)
         torch.cuda.synchronize()
         d = (out != ref).reshape(n, -1).any(1).nonzero().flatten().tolist()
@@ -125,7 +128,7 @@ if mode == "burnstats":
     out0, dbg0 = ras.render(d_rgb, d_depth, hd, n, debug=True); torch.cuda.synchronize()
     for rep in range(3):
         for _ in range(6):
-            lib.salve_debug_burn(1024, 4000, 0, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+            helper.salve_debug_burn(1024, 4000, 0, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
         out, dbg = ras.render(d_rgb, d_depth, hd, n, debug=True)
         torch.cuda.synchronize()
         print("rep", rep, "keys differ", int((dbg.keys != dbg0.keys).sum()), "mask differ", int((dbg.mask != dbg0.mask).sum()),
