@@ -101,6 +101,35 @@ __device__ __forceinline__ void report_range(int32_t* status, float amax) {
 typedef __attribute__((address_space(1))) const void* global_cptr;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+// LDS accesses next to LDS-DMA in flight.  hipcc (ROCm 7.2) puts an `s_waitcnt vmcnt(0)` in front of every LDS access it takes
+// for a possible alias of an LDS-DMA destination -- which drains a prefetch that is meant to stay in flight -- and decides by
+// the access TYPE: loads and stores of _Float16 vectors (the MFMA fragments) are left alone, the same bytes accessed as uint2 /
+// uint4 / float get the wait (checked on small kernels and in the ISA of these, round 3; the fragment reads of every kernel
+// here have always been exempt, which is why the counted waits of conv8_kernel work at all).  The helpers below keep an access
+// typed <n x half> whatever its bits mean: the empty asm makes the value opaque, so the optimiser cannot re-type the load or
+// store from its uses.  Ordering against the LDS-DMA is the caller's business (counted vmcnt + barrier), as for the fragments.
+typedef __attribute__((__ext_vector_type__(4))) _Float16 half4v;
+__device__ __forceinline__ uint2 lds_read8(const uint16_t* p) {
+    half4v t = *reinterpret_cast<const half4v*>(p);
+    asm volatile("" : "+v"(t));
+    return __builtin_bit_cast(uint2, t);
+}
+__device__ __forceinline__ void lds_write8(uint16_t* p, uint2 v) {
+    half4v t = __builtin_bit_cast(half4v, v);
+    asm volatile("" : "+v"(t));
+    *reinterpret_cast<half4v*>(p) = t;
+}
+__device__ __forceinline__ uint4 lds_read16(const uint16_t* p) {
+    act8 t = *reinterpret_cast<const act8*>(p);
+    asm volatile("" : "+v"(t));
+    return __builtin_bit_cast(uint4, t);
+}
+__device__ __forceinline__ float4 lds_read_f4(const float* p) {
+    act8 t = *reinterpret_cast<const act8*>(p);
+    asm volatile("" : "+v"(t));
+    return __builtin_bit_cast(float4, t);
+}
+
 // Staging: `global_load_lds_dwordx4` -- each lane names its own 16 source bytes (the im2col gather), the wave's 1 KiB
 // lands lane-linearly in LDS without passing through VGPRs or the ds_write path.  One wave-instruction fills 8 tile
 // rows of 128 bytes, so the LDS image is unpadded; bank conflicts of the 16-byte fragment reads are avoided by a swizzle
@@ -286,6 +315,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
 #endif
 #include "conv8.h"
 #include "stem_pool.h"
+#include "expand_chain.h"
 
 // 3x3 / stride 2 / pad 1 max-pool on NHWC fp16, 8 channels (16 bytes) per thread.
 __global__ __launch_bounds__(256) void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B,
@@ -524,7 +554,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                     for (int i = 0; i < RT; i++)
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            resid[kt >> 1][i][j] = *reinterpret_cast<const uint2*>(As + res_off[i] + (((2 * j + (frag_q >> 1)) ^ res_swz[i]) << 3));
+                            resid[kt >> 1][i][j] = lds_read8(As + res_off[i] + (((2 * j + (frag_q >> 1)) ^ res_swz[i]) << 3));   // (typed so that no vmcnt(0) lands in front of it: the next k-tile is in flight)
                 }
             }
 #pragma unroll
@@ -807,7 +837,15 @@ struct ResnetHandle {
     bool wide_auto = false;  // the 8-phase kernel only for launches that fill the chip at least twice over (256 x 256 tiles)
     std::vector<int> stem;   // per op: 1 = this 7x7 / 2 convolution and the max-pool behind it run as stem_pool_kernel
     int xcd_contig = 1;      // SALVE_XCD_CONTIG=0: the round-1 mapping (m-tiles dealt round-robin to the XCDs), for A/B runs
+    std::vector<int> chain;  // per op: 1 = this expand convolution (+ residual) runs as expand_chain_kernel, 2 = ... together with
+                             //         the next op, the following block's first 1x1 convolution (expand_chain.h)
+    int n_cus = 256;
+    int chain_dbg = 0, chain_ahead = 2;   // development: SALVE_CHAIN_DBG (timing-only ablations of expand_chain_kernel), SALVE_CHAIN_AHEAD
 };
+
+// expand_chain_kernel shapes: (MID, MIDN) of the chained form, MID of the expand-only form
+static bool chain_shape(int mid, int midn) { return (mid == 128 && (midn == 128 || midn == 256)) || (mid == 256 && midn == 256); }
+static bool expand_shape(int mid) { return mid == 128 || mid == 256; }   // (512: measured 0.80 ms against 0.71 ms for conv8_kernel at batch 4096: compute-bound there)
 
 // SALVE_CONV_WIDE (read when a handle is created): unset = the 8-phase 256 x 256 kernel (conv8.h) on the compute-bound shapes
 // that fit it, 0 = conv_igemm_kernel everywhere, 8 = the 8-phase kernel wherever it fits.  d | e | f select the wide-tile /
@@ -953,6 +991,35 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
             if (dead) { h->fused[i] = shapes ? 1 : 2; i += 2; }
         }
     }
+    h->chain.assign(h->ops.size(), 0);
+    {
+        // SALVE_RESNET_CHAIN: unset / 2 = expand_chain_kernel wherever the shapes allow, chained with the next block's first
+        // convolution where that one follows directly; 1 = the expand convolution only; 0 = the implicit-GEMM kernels
+        const char* e = getenv("SALVE_RESNET_CHAIN");
+        const int mode = e ? atoi(e) : 2;
+        for (size_t i = 0; mode > 0 && i < h->ops.size(); i++) {
+            const salve_resnet_op_t& c = h->ops[i];
+            if (c.op != SALVE_OP_CONV || h->fused[i] || (i >= 1 && h->fused[i - 1]) || (i >= 2 && h->fused[i - 2]) || h->stem[i]) continue;
+            const bool expand = c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad == 0 && c.relu && c.res_buf != SALVE_NO_BUF &&
+                                c.in2_buf == SALVE_NO_BUF && c.Cout == 4 * c.Cin && expand_shape(c.Cin) && c.res_buf != c.out_buf &&
+                                c.in_buf != c.out_buf && c.in_buf >= 0 && c.res_buf >= 0;
+            if (!expand) continue;
+            h->chain[i] = 1;
+            if (mode >= 2 && i + 1 < h->ops.size()) {
+                const salve_resnet_op_t& a = h->ops[i + 1];
+                const bool next = a.op == SALVE_OP_CONV && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.relu &&
+                                  a.res_buf == SALVE_NO_BUF && a.in2_buf == SALVE_NO_BUF && a.in_buf == c.out_buf && a.Cin == c.Cout &&
+                                  a.Hi == c.Ho && a.Wi == c.Wo && chain_shape(c.Cin, a.Cout) && a.out_buf != c.out_buf &&
+                                  a.out_buf != c.in_buf && a.out_buf != c.res_buf && !h->fused[i + 1];
+                if (next) h->chain[i] = 2;
+            }
+        }
+        if (const char* d = getenv("SALVE_CHAIN_DBG")) h->chain_dbg = atoi(d);
+        if (const char* d = getenv("SALVE_CHAIN_AHEAD")) h->chain_ahead = atoi(d);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            h->n_cus = cus;
+    }
     if (hipMalloc(&h->d_weights, weights_bytes) != hipSuccess || hipMalloc(&h->d_params, params_bytes) != hipSuccess ||
         hipMalloc(&h->d_ktab, ktab_entries * sizeof(int32_t)) != hipSuccess || hipMalloc(&h->d_zeros, 256) != hipSuccess) {
         salve_fail("salve_resnet_create: hipMalloc failed");
@@ -1040,6 +1107,37 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             else hipLaunchKernelGGL((bottleneck_kernel<128, 4>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
             SALVE_HIP_CHECK(hipGetLastError());
             oi += 2;
+            continue;
+        }
+        if (o.op == SALVE_OP_CONV && h->chain[oi]) {
+            const bool chained = h->chain[oi] == 2;
+            const salve_resnet_op_t& on = h->ops[chained ? oi + 1 : oi];
+            ChainArgs a;
+            a.t2 = buf(o.in_buf); a.x = buf(o.res_buf); a.y = buf(o.out_buf);
+            a.wc = h->d_weights + o.w_off; a.bc = h->d_params + o.b_off;
+            a.t1n = chained ? buf(on.out_buf) : nullptr;
+            a.wa = chained ? h->d_weights + on.w_off : nullptr;
+            a.ba = chained ? h->d_params + on.b_off : nullptr;
+            a.zeros = h->d_zeros;
+            const long long M = (long long)batch * o.Ho * o.Wo;
+            if (M > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
+            a.M = (int)M;
+            a.n_tiles = (int)((M + 127) / 128);
+            a.status = status;
+            a.dbg = h->chain_dbg;
+            const unsigned grid = (unsigned)(a.n_tiles < h->n_cus ? a.n_tiles : h->n_cus);   // persistent: one workgroup per CU
+            const int mid = o.Cin, midn = chained ? on.Cout : 0;
+            if (chained && mid == 128 && midn == 128 && h->chain_ahead == 3) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 9, true, 3>), dim3(grid), dim3(EC_THREADS), 0, s, a);
+            else if (!chained && mid == 256 && h->chain_ahead == 3) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 10, false, 3>), dim3(grid), dim3(EC_THREADS), 0, s, a);
+            else if (chained && mid == 128 && midn == 128) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 12, true>), dim3(grid), dim3(EC_THREADS), 0, s, a);
+            else if (chained && mid == 128 && midn == 256) hipLaunchKernelGGL((expand_chain_kernel<128, 256, 8, true>), dim3(grid), dim3(EC_THREADS), 0, s, a);
+            else if (chained && mid == 256 && midn == 256) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 5, true>), dim3(grid), dim3(EC_THREADS), 0, s, a);
+            else if (!chained && mid == 128) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 14, false>), dim3(grid), dim3(EC_THREADS), 0, s, a);
+            else if (!chained && mid == 256) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 12, false>), dim3(grid), dim3(EC_THREADS), 0, s, a);
+            else if (!chained && mid == 512) hipLaunchKernelGGL((expand_chain_kernel<512, 512, 6, false>), dim3(grid), dim3(EC_THREADS), 0, s, a);
+            else { salve_fail("expand_chain: unsupported shape"); return SALVE_ERR_UNSUPPORTED; }
+            SALVE_HIP_CHECK(hipGetLastError());
+            if (chained) oi += 1;
             continue;
         }
         if (o.op == SALVE_OP_CONV) {

@@ -3,7 +3,7 @@
 import csv, glob, sys
 d = sys.argv[1]
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv8_kernel", "conv_wide", "conv_pc", "stem_pool", "maxpool", "avgpool", "bottleneck"))]
+rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv8_kernel", "conv_wide", "conv_pc", "stem_pool", "maxpool", "avgpool", "bottleneck", "expand_chain"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n_per = len(rows) // 3   # tools/trace_resnet.py runs three forwards; the last one is reported
 tot = 0
