@@ -256,9 +256,13 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
         if (p.dbg & 4) return;
         const uint16_t* Yc = Ring + prev_slot * EC_ITEM_E;
         char* ybase = reinterpret_cast<char*>(p.y) + prev_m0 * (C4 * 2) + prev_nc * 64;   // wave-uniform
+        act8 vh[2];
+#pragma unroll
+        for (int it = 0; it < 2; it++) vh[it] = *reinterpret_cast<const act8*>(Yc + piece_off[it]);
+        asm volatile("" : "+v"(vh[0]), "+v"(vh[1]));
         uint4 v[2];
 #pragma unroll
-        for (int it = 0; it < 2; it++) v[it] = lds_read16(Yc + piece_off[it]);
+        for (int it = 0; it < 2; it++) v[it] = __builtin_bit_cast(uint4, vh[it]);
         if (prev_m0 + 128 <= p.M) {        // a full tile (wave-uniform): no row guards
 #pragma unroll
             for (int it = 0; it < 2; it++) *reinterpret_cast<uint4*>(ybase + piece_goff[it]) = v[it];
@@ -310,6 +314,10 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
             }
             const uint16_t* Wb = WcB + c_cb * WC_E + b_frag_off;
             f32x4 acc3[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            // the epilogue's LDS reads (bias, residual cell) are issued in front of GEMM 3's: LDS returns in order, so they ride
+            // under the multiply instead of costing a round trip of their own after it
+            act8 bias_h[2];                        // (raw _Float16-typed loads; laundered together below: one asm, one wait)
+            half4v rr_h[2];
             constexpr int KB = KA < 8 ? KA : 8;    // k-steps per batch of fragment reads (16 reads = 64 VGPRs)
 #pragma unroll
             for (int k0 = 0; k0 < KA; k0 += KB) {
@@ -318,6 +326,13 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
                 for (int ks = 0; ks < KB; ks++)
 #pragma unroll
                     for (int j = 0; j < 2; j++) bfr[ks][j] = *reinterpret_cast<const act8*>(Wb + (k0 + ks) * 1024 + j * 512);
+                if (k0 + KB >= KA) {
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        bias_h[j] = *reinterpret_cast<const act8*>(biasc + nc * 32 + 16 * j + 4 * frag_q);
+                        rr_h[j] = *reinterpret_cast<const half4v*>(slot + cell_off[j]);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < KB; ks++)
@@ -326,13 +341,11 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
                 __builtin_amdgcn_sched_barrier(0);
             }
             // bias + residual + ReLU on the accumulator's own elements, in place in the ring slot (fp32, one rounding)
+            asm volatile("" : "+v"(bias_h[0]), "+v"(bias_h[1]), "+v"(rr_h[0]), "+v"(rr_h[1]));   // keeps the four loads <n x half>-typed (lds_read8)
             float4 bias[2];
             uint2 rr[2];
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                bias[j] = lds_read_f4(biasc + nc * 32 + 16 * j + 4 * frag_q);
-                rr[j] = lds_read8(slot + cell_off[j]);
-            }
+            for (int j = 0; j < 2; j++) { bias[j] = __builtin_bit_cast(float4, bias_h[j]); rr[j] = __builtin_bit_cast(uint2, rr_h[j]); }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 float v0 = acc3[j][0] + bias[j].x, v1 = acc3[j][1] + bias[j].y, v2 = acc3[j][2] + bias[j].z, v3 = acc3[j][3] + bias[j].w;
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
                 v2 += act_to_f32((uint16_t)(rr[j].y & 0xFFFFu));
                 v3 += act_to_f32((uint16_t)(rr[j].y >> 16));
                 v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                track4(amax, v0, v1, v2, v3);
+                amax = fmaxf(fmaxf(amax, v0), fmaxf(v1, fmaxf(v2, v3)));   // (after the ReLU: no |.| needed)
                 uint2 o;
                 o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
                 o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
