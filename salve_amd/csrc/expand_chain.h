@@ -37,8 +37,7 @@
 //     H = {0, 3, 1, 2} -- conflict-free for gfx950's ds_read_b128 lane groups (rows 4 apart share banks), applied on the
 //     SOURCE side of the LDS-DMA (the destination is lane-linear).
 // Bit-identical to the two-kernel path: same k order, fp32 accumulation, one rounding of Y to fp16 before it is used again.
-constexpr int EC_THREADS = 512;
-constexpr int EC_ITEM_E = 128 * 32;   // uint16 elements of a ring item
+// NW = waves per workgroup (8 or 16): a tile is 16 NW pixels (a wave owns 16), a ring item 16 NW rows x 32 halves.
 
 struct ChainArgs {
     const uint16_t* t2;    // [M][MID]
@@ -64,8 +63,10 @@ __device__ __forceinline__ int ec_src_chunk(int row, int slot) {   // which k-ch
     return (0x78 >> (2 * v)) & 3;                           // the inverse of H: {0, 2, 3, 1}
 }
 
-template <int MID, int MIDN, int R, bool CHAIN, int AHEAD = 2>
-__global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p) {
+template <int MID, int MIDN, int R, bool CHAIN, int AHEAD = 2, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs p) {
+    constexpr int EC_THREADS = NW * 64, ROWS = NW * 16, EC_ITEM_E = ROWS * 32;
+    constexpr int NL = NW / 2;              // loader waves (0 .. NL - 1); the others are the storers
     constexpr int C4 = 4 * MID;
     constexpr int KA = MID / 32;            // A items (k-steps of t2) per tile
     constexpr int NCH = C4 / 32;            // RES items (chunks of Y) per tile
@@ -73,9 +74,10 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
     constexpr int WC_E = 32 * MID;          // one Wc chunk: [KA][32 rows][32]
     constexpr int WA_E = CHAIN ? MIDN * 32 : 0;   // one Wa' chunk: [MIDN rows][32]
     constexpr int NT1 = CHAIN ? MIDN / 16 : 1;    // GEMM 1': 16-channel tiles of a storer wave (all of them)
-    constexpr int WC_DMA = 2 * KA / 4;      // LDS-DMA instructions per loader wave: Wc chunk (1 KB each) ...
-    constexpr int WA_DMA = CHAIN ? MIDN / 16 / 4 : 0;   // ... Wa' chunk ...
-    constexpr int IT_DMA = 2;               // ... ring item (8 KB over 4 waves)
+    constexpr int WC_DMA = 2 * KA / NL;     // LDS-DMA instructions per loader wave: Wc chunk (1 KB each) ...
+    constexpr int WA_DMA = CHAIN ? MIDN / 16 / NL : 0;  // ... Wa' chunk ...
+    constexpr int IT_DMA = (ROWS / 16) / NL;            // ... ring item
+    static_assert(2 * KA % NL == 0 && (!CHAIN || (MIDN / 16) % NL == 0) && IT_DMA == 2, "LDS-DMA split over the loader waves");
     constexpr int NB_C = AHEAD + 1, NB_A = AHEAD + 2;   // Wc / Wa' buffers: a chunk is issued AHEAD RES steps ahead into the buffer read last one / two steps ago
     constexpr int SMEM_E = NB_C * WC_E + NB_A * WA_E + R * EC_ITEM_E + 2 * (C4 + (CHAIN ? MIDN : 0));
     static_assert(R >= 4, "an item must be older than the previous step's issue when it is consumed");
@@ -90,8 +92,8 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frag_row = lane & 15, frag_q = lane >> 4;
-    const bool loader = wave < 4;
-    const int sw = wave & 3;                 // index among the loaders / among the storers
+    const bool loader = wave < NL;
+    const int sw = wave % NL;                // index among the loaders / among the storers
     // this workgroup's tiles: b, b + G, b + 2 G, ...
     const int G = gridDim.x, b = blockIdx.x;
     const int n_my = b < p.n_tiles ? (p.n_tiles - b + G - 1) / G : 0;
@@ -126,9 +128,9 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
     const char* it_base_a = nullptr;               // wave-uniform: t2 / x at the producer's tile
     const char* it_base_x = nullptr;
     auto producer_tile = [&]() {
-        const long long m0 = ((long long)b + (long long)p_ti * G) * 128;
+        const long long m0 = ((long long)b + (long long)p_ti * G) * ROWS;
         const long long left = (long long)p.M - m0;
-        const int rows = left >= 128 ? 128 : (left > 0 ? (int)left : 1);
+        const int rows = left >= ROWS ? ROWS : (left > 0 ? (int)left : 1);
         const long long mb = left > 0 ? m0 : 0;    // (a tile past the end of the stream: any valid rows, nobody reads the slot)
         it_base_a = reinterpret_cast<const char*>(p.t2) + mb * (MID * 2);
         it_base_x = reinterpret_cast<const char*>(p.x) + mb * (C4 * 2);
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
     uint32_t piece_goff[2];                                         // ... and their byte offsets in Y relative to the tile's chunk
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-        const int piece = it * 256 + sw * 64 + lane, row = piece >> 2, q = piece & 3;
+        const int piece = it * (NL * 64) + sw * 64 + lane, row = piece >> 2, q = piece & 3;
         piece_off[it] = ec_slot(row, q);
         piece_goff[it] = (uint32_t)((row * C4 + q * 8) * 2);
     }
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
             // all fragment reads of a batch first, then its MFMAs: left to itself hipcc re-uses one register quad for every
             // B fragment and emits read -> wait -> MFMA per tile, i.e. an LDS round trip in front of every MFMA
             const act8 ay = *reinterpret_cast<const act8*>(Yc + a_frag_off);
-            constexpr int NB = NT1 < 16 ? NT1 : 16;
+            constexpr int NB = NW == 16 ? 4 : (NT1 < 16 ? NT1 : 16);   // (16 waves: 128 registers per lane -- smaller batches)
 #pragma unroll
             for (int n0 = 0; n0 < NT1; n0 += NB) {
                 act8 bn[NB];
@@ -263,13 +265,13 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
         uint4 v[2];
 #pragma unroll
         for (int it = 0; it < 2; it++) v[it] = __builtin_bit_cast(uint4, vh[it]);
-        if (prev_m0 + 128 <= p.M) {        // a full tile (wave-uniform): no row guards
+        if (prev_m0 + ROWS <= p.M) {       // a full tile (wave-uniform): no row guards
 #pragma unroll
             for (int it = 0; it < 2; it++) *reinterpret_cast<uint4*>(ybase + piece_goff[it]) = v[it];
         } else {
 #pragma unroll
             for (int it = 0; it < 2; it++) {
-                const int row = (it * 256 + sw * 64 + lane) >> 2;
+                const int row = (it * (NL * 64) + sw * 64 + lane) >> 2;
                 if (prev_m0 + row < p.M) *reinterpret_cast<uint4*>(ybase + piece_goff[it]) = v[it];
             }
         }
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
     };
 
     for (int ti = 0; ti < n_my; ti++) {
-        const long long m0 = ((long long)b + (long long)ti * G) * 128;
+        const long long m0 = ((long long)b + (long long)ti * G) * ROWS;
         // ---------------------------------------------------------------- A items: the tile's A fragments -> registers
 #pragma unroll
         for (int k = 0; k < KA; k++) {
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(EC_THREADS, 2) void expand_chain_kernel(ChainArgs p
             // under the multiply instead of costing a round trip of their own after it
             act8 bias_h[2];                        // (raw _Float16-typed loads; laundered together below: one asm, one wait)
             half4v rr_h[2];
-            constexpr int KB = KA < 8 ? KA : 8;    // k-steps per batch of fragment reads (16 reads = 64 VGPRs)
+            constexpr int KB = NW == 16 ? 2 : (KA < 8 ? KA : 8);   // k-steps per batch of fragment reads (16 reads = 64 VGPRs)
 #pragma unroll
             for (int k0 = 0; k0 < KA; k0 += KB) {
                 act8 bfr[KB][2];

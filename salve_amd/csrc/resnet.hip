@@ -840,7 +840,7 @@ struct ResnetHandle {
     std::vector<int> chain;  // per op: 1 = this expand convolution (+ residual) runs as expand_chain_kernel, 2 = ... together with
                              //         the next op, the following block's first 1x1 convolution (expand_chain.h)
     int n_cus = 256;
-    int chain_dbg = 0, chain_ahead = 2;   // development: SALVE_CHAIN_DBG (timing-only ablations of expand_chain_kernel), SALVE_CHAIN_AHEAD
+    int chain_dbg = 0, chain_waves = 8;   // development: SALVE_CHAIN_DBG (timing-only ablations of expand_chain_kernel), SALVE_CHAIN_WAVES = 8 | 16
 };
 
 // expand_chain_kernel shapes: (MID, MIDN) of the chained form, MID of the expand-only form
@@ -1015,7 +1015,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
             }
         }
         if (const char* d = getenv("SALVE_CHAIN_DBG")) h->chain_dbg = atoi(d);
-        if (const char* d = getenv("SALVE_CHAIN_AHEAD")) h->chain_ahead = atoi(d);
+        if (const char* d = getenv("SALVE_CHAIN_WAVES")) h->chain_waves = atoi(d);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             h->n_cus = cus;
@@ -1122,19 +1122,25 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             const long long M = (long long)batch * o.Ho * o.Wo;
             if (M > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
             a.M = (int)M;
-            a.n_tiles = (int)((M + 127) / 128);
             a.status = status;
             a.dbg = h->chain_dbg;
-            const unsigned grid = (unsigned)(a.n_tiles < h->n_cus ? a.n_tiles : h->n_cus);   // persistent: one workgroup per CU
             const int mid = o.Cin, midn = chained ? on.Cout : 0;
-            if (chained && mid == 128 && midn == 128 && h->chain_ahead == 3) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 9, true, 3>), dim3(grid), dim3(EC_THREADS), 0, s, a);
-            else if (!chained && mid == 256 && h->chain_ahead == 3) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 10, false, 3>), dim3(grid), dim3(EC_THREADS), 0, s, a);
-            else if (chained && mid == 128 && midn == 128) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 12, true>), dim3(grid), dim3(EC_THREADS), 0, s, a);
-            else if (chained && mid == 128 && midn == 256) hipLaunchKernelGGL((expand_chain_kernel<128, 256, 8, true>), dim3(grid), dim3(EC_THREADS), 0, s, a);
-            else if (chained && mid == 256 && midn == 256) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 5, true>), dim3(grid), dim3(EC_THREADS), 0, s, a);
-            else if (!chained && mid == 128) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 14, false>), dim3(grid), dim3(EC_THREADS), 0, s, a);
-            else if (!chained && mid == 256) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 12, false>), dim3(grid), dim3(EC_THREADS), 0, s, a);
-            else if (!chained && mid == 512) hipLaunchKernelGGL((expand_chain_kernel<512, 512, 6, false>), dim3(grid), dim3(EC_THREADS), 0, s, a);
+            // SALVE_CHAIN_WAVES=16: 16 waves, tiles of 256 pixels, where the registers allow it (<= 128 per lane).  Four waves per SIMD
+            // issue more densely than two -- with every memory operation switched off the layer-2 launch takes 1.22 instead of
+            // 1.55 ms -- but with them it takes the same 1.95 ms: at 4.1 TB/s of mixed reads and writes in 64-byte row pieces the
+            // memory system is what is left.  Bit-identical; not the default.
+            const bool wide = h->chain_waves == 16 && mid == 128 && (!chained || midn == 128);
+            const int rows = wide ? 256 : 128;
+            a.n_tiles = (int)((M + rows - 1) / rows);
+            const unsigned grid = (unsigned)(a.n_tiles < h->n_cus ? a.n_tiles : h->n_cus);   // persistent: one workgroup per CU
+            const dim3 blk(wide ? 1024 : 512);
+            if (wide && chained) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 6, true, 2, 16>), dim3(grid), blk, 0, s, a);
+            else if (wide) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 7, false, 2, 16>), dim3(grid), blk, 0, s, a);
+            else if (chained && mid == 128 && midn == 128) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 12, true>), dim3(grid), blk, 0, s, a);
+            else if (chained && mid == 128 && midn == 256) hipLaunchKernelGGL((expand_chain_kernel<128, 256, 8, true>), dim3(grid), blk, 0, s, a);
+            else if (chained && mid == 256 && midn == 256) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 5, true>), dim3(grid), blk, 0, s, a);
+            else if (!chained && mid == 128) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 14, false>), dim3(grid), blk, 0, s, a);
+            else if (!chained && mid == 256) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 12, false>), dim3(grid), blk, 0, s, a);
             else { salve_fail("expand_chain: unsupported shape"); return SALVE_ERR_UNSUPPORTED; }
             SALVE_HIP_CHECK(hipGetLastError());
             if (chained) oi += 1;

@@ -238,8 +238,9 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(monke
     x = torch.randn(batch, 224, 224, cin).to(torch.float16).to(DEV)
     x[..., (6 if layers == 50 else 12):] = 0
     outs = {}
-    for mode in ("0", "1", "2"):
-        monkeypatch.setenv("SALVE_RESNET_CHAIN", mode)   # read when the handle is created
+    for mode in ("0", "1", "2", "2w"):
+        monkeypatch.setenv("SALVE_RESNET_CHAIN", mode[0])   # read when the handle is created
+        monkeypatch.setenv("SALVE_CHAIN_WAVES", "16" if mode.endswith("w") else "8")   # "2w": the 16-wave / 256-pixel-tile variant
         eng = hip_resnet.HipResNet(model.state_dict(), layers, torch.device(DEV))
         for rep in range(3):                             # a misplaced wait in a ring shows up as a rare wrong tile: repeat
             o = eng.forward_nhwc(x).clone()
@@ -251,6 +252,7 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(monke
     status.check(DEV, "expand_chain test")
     assert torch.equal(outs["1"], outs["0"]), "expand-only kernel differs from the implicit-GEMM path"
     assert torch.equal(outs["2"], outs["0"]), "chained kernel differs from the implicit-GEMM path"
+    assert torch.equal(outs["2w"], outs["0"]), "16-wave chained kernel differs from the implicit-GEMM path"
 
 
 def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool(monkeypatch):
