@@ -8,7 +8,7 @@ in KiB units of 1024 B... the counter reports kilobytes), L2 hit rate and MFMA-b
 usage: resnet_traffic_report.py <dir> <batch>"""
 import collections, csv, glob, json, sys
 d, B = sys.argv[1], int(sys.argv[2])
-VER = ("conv_igemm", "conv8_kernel", "conv_wide", "conv_pc", "bottleneck", "stem_pool", "maxpool", "avgpool", "pw_", "block_")
+VER = ("conv_igemm", "conv8_kernel", "conv_wide", "conv_pc", "bottleneck", "stem_pool", "maxpool", "avgpool", "expand_chain")
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 def trace(sub):
@@ -58,12 +58,15 @@ print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 oi = 0
 tot = collections.Counter()
 for i, (name, us) in enumerate(launches):
-    take = 3 if ("bottleneck" in name or "block_" in name) else (2 if "stem_pool" in name else 1)
+    take = 3 if "bottleneck" in name else (2 if ("stem_pool" in name or ("expand_chain" in name and ", true" in name)) else 1)
     mine = ops[oi:oi + take]; oi += take
     fl = sum(op_cost(o)[0] for o in mine) * B
     if take == 3:    # fused block: input + residual (the same tensor: once) + output
         a, c = mine[0], mine[2]
         by = (a["Hi"] * a["Wi"] * a["Cin"] * 2 + c["Ho"] * c["Wo"] * c["Cout"] * 2) * B
+    elif take == 2 and "expand_chain" in name:  # expand + residual + next reduce: t2 and X in, Y and t1' out (Y is not read back)
+        c, a = mine
+        by = (c["Hi"] * c["Wi"] * c["Cin"] * 2 + 2 * c["Ho"] * c["Wo"] * c["Cout"] * 2 + a["Ho"] * a["Wo"] * a["Cout"] * 2) * B
     elif take == 2:  # stem + pool: input + pooled output
         by = (mine[0]["Hi"] * mine[0]["Wi"] * mine[0]["Cin"] * 2 + mine[1]["Ho"] * mine[1]["Wo"] * mine[1]["Cout"] * 2) * B
     else:
