@@ -19,6 +19,7 @@
 // table products, the FMA order of numpy's BLAS matmul, half-to-even rounding); everything after the pixel index
 // is integer arithmetic.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -95,16 +96,32 @@ struct DensifyCfg {
 __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
     DevCfg c, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, const double* __restrict__ sphere,
     const salve_bev_hyp_t* __restrict__ hyps, uint32_t* __restrict__ keys, const uint8_t** __restrict__ colour_src,
-    int16_t* __restrict__ dbg_xy, int32_t* __restrict__ in_window, int32_t* __restrict__ bbox, int pass) {
-    const int rid = blockIdx.y;
+    int16_t* __restrict__ dbg_xy, int32_t* __restrict__ in_window, int32_t* __restrict__ bbox, int pass, int n_renders, int n_chunks, int xcd_group) {
+    // Workgroup -> (render, chunk of the panorama).  All workgroups of a render scatter into ONE 1 MB key image with 4-byte
+    // stores / loads / atomics at random cells.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with an
+    // L2 of its own: in the natural order (chunk fastest) a render's key image is written in 32-byte sector pieces from eight
+    // L2s; with `xcd_group` a render's workgroups all carry the same id % 8, so its key image lives in one L2 for the pass
+    // (render = 8 * (s / n_chunks) + id % 8, chunk = s % n_chunks, s = id / 8).  Round 3 measured the grouped order SLOWER
+    // (11.8 against 8.6 ms per 4096 renders): the scattered stores and atomics of a render then queue at one L2 instead of
+    // eight.  The natural order is the default; the grouped one stays selectable (SALVE_RAS_XCD bit 0) for the record.
+    int rid, chunk_id;
+    if (xcd_group) {
+        const int id = blockIdx.x, s_ = id >> 3;
+        rid = (s_ / n_chunks) * 8 + (id & 7);
+        chunk_id = s_ % n_chunks;
+        if (rid >= n_renders) return;
+    } else {
+        rid = blockIdx.x / n_chunks;
+        chunk_id = blockIdx.x % n_chunks;
+    }
     const salve_bev_hyp_t h = hyps[rid];
     // where the densify kernel finds the colour of point index i of this render: colour_src[rid] + 3 i
-    if (blockIdx.x == 0 && threadIdx.x == 0) colour_src[rid] = rgb + ((size_t)h.pano_idx * c.pano_h + c.crop_rows) * c.pano_w * 3;
-    const int p0 = (blockIdx.x * SCATTER_THREADS + threadIdx.x) * PTS_PER_THREAD;  // first point (cropped raster)
+    if (chunk_id == 0 && threadIdx.x == 0) colour_src[rid] = rgb + ((size_t)h.pano_idx * c.pano_h + c.crop_rows) * c.pano_w * 3;
+    const int p0 = (chunk_id * SCATTER_THREADS + threadIdx.x) * PTS_PER_THREAD;  // first point (cropped raster)
     {   // Dead rows: z = d * zdir(v) with d >= 0 has the sign of zdir(v), so above the horizon no point can be floor and below
         // it none can be ceiling -- half of the panorama's rows for either surface.  If every row this workgroup touches
         // is dead for the render's z range, it has nothing to do (uniform exit, before any barrier).
-        const int pb = blockIdx.x * SCATTER_THREADS * PTS_PER_THREAD;
+        const int pb = chunk_id * SCATTER_THREADS * PTS_PER_THREAD;
         const int v_first = pb / c.pano_w + c.crop_rows;
         const int v_last = min(pb + SCATTER_THREADS * PTS_PER_THREAD - 1, c.npts - 1) / c.pano_w + c.crop_rows;
         const double* zd_ = sphere + c.pano_h;
@@ -915,9 +932,21 @@ __device__ __forceinline__ void tile_pixel(const uint32_t* __restrict__ img, int
 __global__ __launch_bounds__(256) void bev_tile_pair_kernel(const uint32_t* __restrict__ bev_a, const uint32_t* __restrict__ bev_b, int W,
                                                             const salve_tile_job_t* __restrict__ jobs_a, const salve_tile_job_t* __restrict__ jobs_b,
                                                             const int32_t* __restrict__ coef_y, const int32_t* __restrict__ coef_x, int resize,
-                                                            int crop, const float* __restrict__ lut, uint16_t* __restrict__ out, int out_c) {
-    const salve_tile_job_t ja = jobs_a[blockIdx.y], jb = jobs_b[blockIdx.y];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+                                                            int crop, const float* __restrict__ lut, uint16_t* __restrict__ out, int out_c,
+                                                            int n_pairs, int n_blocks, int xcd_group) {
+    // (the workgroups of one pair read the same two BEV images: same id % 8 = same XCD = one L2 -- as in bev_scatter_kernel)
+    int job, blk;
+    if (xcd_group) {
+        const int id = blockIdx.x, s_ = id >> 3;
+        job = (s_ / n_blocks) * 8 + (id & 7);
+        blk = s_ % n_blocks;
+        if (job >= n_pairs) return;
+    } else {
+        job = blockIdx.x / n_blocks;
+        blk = blockIdx.x % n_blocks;
+    }
+    const salve_tile_job_t ja = jobs_a[job], jb = jobs_b[job];
+    const int idx = blk * 256 + threadIdx.x;
     if (idx >= crop * crop) return;
     const int i = idx / crop, j = idx % crop;
     const int off = (resize - crop) / 2;
@@ -1180,7 +1209,13 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         // (no clear of the key images: salve_bev_workspace_init zeroed them and every densify re-zeroes what it read)
         SALVE_HIP_CHECK(hipMemsetAsync(ws.bbox, 0, (size_t)n * 4 * sizeof(int32_t), s));
         const int pts_per_block = SCATTER_THREADS * PTS_PER_THREAD;
-        dim3 g1((d.npts + pts_per_block - 1) / pts_per_block, n);
+        const int n_chunks = (d.npts + pts_per_block - 1) / pts_per_block;
+        // SALVE_RAS_XCD bit 0 (default off): measured at the benchmark's shape 11.8 ms per 4096 renders grouped against 8.6 ms in the
+        // natural order -- one L2 then serialises a render's 74 k scattered stores and its atomics, eight share them
+        static const int xcd_group = [] { const char* e = getenv("SALVE_RAS_XCD"); return e ? (atoi(e) & 1) : 0; }();
+        const long long n_wg = (long long)(xcd_group ? (n + 7) / 8 * 8 : n) * n_chunks;
+        if (n_wg > 0x7FFFFFFFll) { salve_fail("too many renders for one scatter launch"); return SALVE_ERR_BAD_ARG; }
+        dim3 g1((unsigned)n_wg);
         if (in_window) SALVE_HIP_CHECK(hipMemsetAsync(in_window, 0, (size_t)n * sizeof(int32_t), s));
         // Two passes instead of one atomicMax per point (a device-scope atomic is a 64-byte request to the memory side;
         // 52 k of them per render were 80 % of this stage): pass 0 stores keys with plain stores -- for a pixel with
@@ -1189,7 +1224,7 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         // then takes part in the atomic maximum: the result is the maximum over all contenders.
         for (int pass = 0; pass < 2; pass++) {
             hipLaunchKernelGGL(bev_scatter_kernel, g1, dim3(SCATTER_THREADS), 0, s, d, pano_rgb, pano_depth, sphere, hyps, ws.keys,
-                               ws.colour_src, dbg_img_xy, in_window, ws.bbox, pass);
+                               ws.colour_src, dbg_img_xy, in_window, ws.bbox, pass, n, n_chunks, xcd_group);
             SALVE_HIP_CHECK(hipGetLastError());
         }
     }
@@ -1372,9 +1407,11 @@ int salve_bev_tile_pairs(const uint32_t* bev_a, const uint32_t* bev_b, int32_t b
     }
     if (crop <= 0 || resize < crop || out_c < 6 || out_c % 2 != 0) { salve_fail("salve_bev_tile_pairs: need 0 < crop <= resize, even out_c >= 6"); return SALVE_ERR_BAD_ARG; }
     if (n_pairs > 65535) { salve_fail("at most 65535 tile pairs per call"); return SALVE_ERR_BAD_ARG; }
-    dim3 g((crop * crop + 255) / 256, n_pairs);
+    const int n_blocks = (crop * crop + 255) / 256;
+    static const int xcd_group = [] { const char* e = getenv("SALVE_RAS_XCD"); return e ? ((atoi(e) >> 1) & 1) : 1; }();   // bit 1 (default on)
+    dim3 g((unsigned)((xcd_group ? (n_pairs + 7) / 8 * 8 : n_pairs) * n_blocks));
     hipLaunchKernelGGL(bev_tile_pair_kernel, g, dim3(256), 0, (hipStream_t)stream, bev_a, bev_b, bev_w, jobs_a, jobs_b, coef_y, coef_x,
-                       resize, crop, lut, reinterpret_cast<uint16_t*>(out), out_c);
+                       resize, crop, lut, reinterpret_cast<uint16_t*>(out), out_c, n_pairs, n_blocks, xcd_group);
     SALVE_HIP_CHECK(hipGetLastError());
     return SALVE_OK;
 }
