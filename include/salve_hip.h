@@ -171,8 +171,11 @@ int salve_resize_rgb_u8(const uint8_t* src, int32_t n, int32_t src_h, int32_t sr
  *   segs     device int32 [*, 8]: x1, y1, x2, y2, colour 0x00BBGGRR, thickness in pixels, 0, 0
  *   out      device uint32 [n, img_h, img_w], 0x00BBGGRR (the layout of salve_bev_render_batch's out_bev: salve_bev_tiles and
  *            salve_bev_export_u8 take it as is)
- * OpenCV's own pixel arithmetic is not installed here and not pinned by the reference's tests: the integer rules implemented
- * are stated in oracle/layout_oracle.py ("parity unpinned"). */
+ * The pixel rules are OpenCV 4.x's (modules/imgproc/src/drawing.cpp): fillPoly with its defaults for the polygon; for a segment
+ * ThickLine with LINE_AA -- an anti-aliased convex quadrilateral (FillConvexPoly: LineAA along the edges, then spans) plus an
+ * anti-aliased 12-gon end cap (EllipseEx / ellipse2Poly at 30 degrees) at either end, LineAA's filter and slope tables, every
+ * anti-aliased pixel blended twice; thickness <= 1 is one LineAA.  cv2 is not installed here and the reference's tests pin none
+ * of it: the restatement is in oracle/layout_oracle.py ("parity unpinned"), the kernel is bit-exact against it. */
 typedef struct {
     int32_t n_poly, poly_off; /* vertex count and first vertex of this image's polygon in poly_xy */
     int32_t n_seg, seg_off;   /* segment count and first segment in segs */

@@ -66,9 +66,13 @@ def rasterise_layouts(specs: Sequence[LayoutSpec], device, bev_params: Optional[
         rec[i]["n_seg"] = len(segs) - rec[i]["seg_off"]
     poly_np = np.concatenate(polys).astype(np.int32) if polys else np.zeros((1, 2), np.int32)
     seg_np = np.array(segs, dtype=np.int64).astype(np.int32).reshape(-1, 8) if segs else np.zeros((1, 8), np.int32)
-    # pixel coordinates of far-away geometry can exceed int32 after the squares in the kernel: clamp to a generous range
-    poly_np = np.clip(poly_np, -20000, 20000)
-    seg_np[:, :4] = np.clip(seg_np[:, :4], -20000, 20000)
+    # The kernel clips geometrically (OpenCV's clipLine in 64-bit fixed point; the polygon rules in 64-bit integers): coordinates
+    # are NOT clamped per axis -- that would change the slopes of edges that cross the image.  Only absurd values are refused.
+    if segs and int(seg_np[:, 5].max()) >= 19:
+        raise ValueError("lines of 19 pixels and more need OpenCV's end caps at 18- / 5-degree steps, which the kernel does not draw "
+                         "(the reference draws 8- and 2-pixel lines: bevparams.get_line_width_by_resolution(0.02))")
+    if max(int(np.abs(poly_np).max(initial=0)), int(np.abs(seg_np[:, :4]).max(initial=0))) > (1 << 24):
+        raise ValueError("layout geometry more than 2^24 pixels away from the image: not a room layout")
     d_rec = torch.from_numpy(rec.view(np.uint8)).to(device)
     d_poly = torch.from_numpy(np.ascontiguousarray(poly_np)).to(device)
     d_seg = torch.from_numpy(np.ascontiguousarray(seg_np)).to(device)

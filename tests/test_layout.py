@@ -49,19 +49,47 @@ def test_fill_poly_rules():
     poly = np.array([[5, 5], [50, 5], [50, 50], [28, 20], [5, 50]])
     lo.fill_poly(img, poly, (255, 255, 255))
     assert not img[45, 28].any() and img[10, 28].all() and img[50, 5].all() and img[50, 50].all()
-    # integer square root and the distance in 1/256 pixels
-    for v in (0, 1, 2, 3, 4, 15, 16, 17, 2 ** 40 + 12345, 2 ** 62 - 1):
-        r = lo.isqrt64(v)
-        assert r * r <= v < (r + 1) * (r + 1)
-    assert lo.segment_distance_256(0, 3, 0, 0, 10, 0) == 768 and lo.segment_distance_256(13, 4, 0, 0, 10, 0) == 1280
 
 
-def test_thick_line_coverage_and_layout_image():
+def test_opencv_thick_line_rules():
+    """The restated ThickLine (oracle/layout_oracle.py: parity unpinned, OpenCV 4.x drawing.cpp).  Properties any faithful
+    restatement has, checked on an axis-aligned 8-pixel line: the quadrilateral p +- (0, 4 px) fills rows 16 .. 24 completely
+    between the end points (FillConvexPoly fills ceil(left) .. floor(right) of the scanlines ymin .. ymax inclusive), its
+    anti-aliased edges leave a soft pixel row above and below, the end caps are 12-gons of radius 4 -- rounded, symmetric --
+    and the geometry is exactly ThickLine's: dp = cvRound(perpendicular * 4 px) in 16.16 fixed point."""
+    quad, th, p0, p1 = lo.thick_line_geometry(10, 20, 50, 20, 8)
+    one = 1 << 16
+    assert th == 4 * one and p0 == (10 * one, 20 * one) and p1 == (50 * one, 20 * one)
+    assert quad == [(10 * one, 16 * one), (10 * one, 24 * one), (50 * one, 24 * one), (50 * one, 16 * one)]   # dp = (0, -4 px): dx = p0.x - p1.x < 0
+    cap = lo.cv_ellipse_poly(100 * one, 100 * one, 4 * one)
+    assert len(cap) == 13 and cap[0] == cap[12] == (104 * one, 100 * one) and cap[3] == (100 * one, 104 * one)
+    assert cap[1] == (100 * one + 227023, 102 * one) and cap[2] == (102 * one, 100 * one + 227023)   # 4 * 0.8660254 = 3.4641016 px
     img = np.zeros((40, 60, 3), np.uint8)
-    lo.thick_line_aa(img, 10, 20, 50, 20, (0, 255, 0), 8)
+    lo.cv_thick_line_aa(img, 10, 20, 50, 20, (0, 255, 0), 8)
     col = img[:, 30, 1].astype(int)
-    assert (col[17:24] == 255).all() and col[16] == 128 and col[24] == 128 and col[15] == 0 and col[25] == 0   # 8 px wide, soft rim
-    assert img[20, 5, 1] > 0 and img[20, 4, 1] == 0 or img[20, 6, 1] > 0                                       # round caps
+    assert (col[16:25] == 255).all() and col[14] == 0 and col[26] == 0 and 0 < col[15] < 128 and 0 < col[25] < 128   # (the filter's two tails differ: 48 and 53 at dist 16)
+    row = img[20, :, 1].astype(int)
+    assert (row[6:55] == 255).all() and row[4] == 0 and row[56] == 0                 # caps reach 4 px beyond the end points
+    assert 380 <= int((img[..., 1] == 255).sum()) <= 470                             # a 40 x 9 bar + two discs of radius 4
+    assert not img[..., 0].any() and not img[..., 2].any()
+    # a zero-length segment draws its two (identical) caps only; thickness 1 is a single LineAA
+    dot = np.zeros((30, 30, 3), np.uint8)
+    lo.cv_thick_line_aa(dot, 15, 15, 15, 15, (255, 255, 255), 8)
+    assert dot[15, 15].all() and dot[15, 11].all() and dot[15, 19].all() and not dot[15, 9].any() and not dot[9, 15].any()
+    thin = np.zeros((30, 30, 3), np.uint8)
+    lo.cv_thick_line_aa(thin, 5, 5, 25, 12, (255, 255, 255), 1)
+    assert 20 < (thin[..., 0] > 0).sum() < 80 and thin.max() <= 255
+
+
+def test_clip_line_fixed_point():
+    W = H = 100 << 16
+    assert lo.clip_line_fixed(W, H, 5 << 16, 5 << 16, 50 << 16, 60 << 16) == (5 << 16, 5 << 16, 50 << 16, 60 << 16)
+    assert lo.clip_line_fixed(W, H, -(10 << 16), -(10 << 16), -(5 << 16), 50 << 16) is None
+    x1, y1, x2, y2 = lo.clip_line_fixed(W, H, -(10 << 16), 50 << 16, 200 << 16, 50 << 16)
+    assert (x1, y1, x2, y2) == (0, 50 << 16, W - 1, 50 << 16)
+
+
+def test_layout_image():
     room = np.array([[-1.5, -1.0], [2.0, -1.2], [2.2, 0.5], [0.8, 0.6], [0.7, 1.9], [-1.4, 1.8]])
     wdos = [("doors", np.array([[2.0, -1.2], [2.1, -0.4]])), ("windows", np.array([[-1.5, -0.5], [-1.45, 0.6]]))]
     out = lo.rasterize_single_layout(room, wdos)
@@ -95,14 +123,20 @@ def test_layout_kernel_matches_oracle_bit_for_bit():
             wdos.append((("doors", "windows", "openings")[j % 3], np.stack([p + t0 * (q - p), p + t1 * (q - p)])))
         specs.append((np.vstack([room, room[:1]]), wdos))
     specs.append((np.array([[-9.0, -9.0], [9.0, -9.0], [9.0, 9.0], [-9.0, 9.0]]), [("doors", np.array([[-20.0, 0.0], [20.0, 0.3]]))]))  # beyond the image
+    # seventeen segments in one image (the kernel sets its primitives up in chunks of seven), crossing one another -- the blends
+    # are order dependent --, one of zero length (end caps only), one leaving the image through a corner
+    star = [(("doors", "windows", "openings")[j % 3], np.array([[0.3 * np.cos(j), 0.3 * np.sin(j)], [2.5 * np.cos(j * 0.7), 2.5 * np.sin(j * 0.7)]])) for j in range(15)]
+    star += [("doors", np.array([[1.0, 1.0], [1.0, 1.0]])), ("windows", np.array([[2.9, 2.9], [4.5, 4.4]]))]
+    specs.append((np.array([[-3.0, -3.0], [3.0, -3.0], [3.0, 3.0], [-3.0, 3.0], [-3.0, -3.0]]), star))
     dev = torch.device("cuda:0")
-    got = layout.rasterise_layouts(specs, dev)
     from salve_amd.rasteriser import BevRasteriser
 
-    u8 = BevRasteriser(dev).export_u8(got).cpu().numpy()
-    for k, (room, wdos) in enumerate(specs):
-        exp = lo.rasterize_single_layout(room, wdos)
-        assert np.array_equal(u8[k], exp), f"layout {k}"
+    for render_mask in (True, False):   # False: the room as a 2-pixel anti-aliased contour instead of the filled mask (:128-136)
+        got = layout.rasterise_layouts(specs, dev, render_mask=render_mask)
+        u8 = BevRasteriser(dev).export_u8(got).cpu().numpy()
+        for k, (room, wdos) in enumerate(specs):
+            exp = lo.rasterize_single_layout(room, wdos, render_mask=render_mask)
+            assert np.array_equal(u8[k], exp), f"layout {k}, render_mask {render_mask}: {int((u8[k] != exp).any(-1).sum())} pixels differ"
 
 
 @gpu
