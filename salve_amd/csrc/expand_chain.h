@@ -37,7 +37,11 @@
 //     H = {0, 3, 1, 2} -- conflict-free for gfx950's ds_read_b128 lane groups (rows 4 apart share banks), applied on the
 //     SOURCE side of the LDS-DMA (the destination is lane-linear).
 // Bit-identical to the two-kernel path: same k order, fp32 accumulation, one rounding of Y to fp16 before it is used again.
-// NW = waves per workgroup (8 or 16): a tile is 16 NW pixels (a wave owns 16), a ring item 16 NW rows x 32 halves.
+// NW = waves per workgroup (8 or 16), NSPLIT = waves that share a 16-pixel row tile (1 or 2): a tile is 16 NW / NSPLIT pixels, a
+// ring item that many rows x 32 halves.  With NSPLIT = 2 (16 waves on a 128-pixel tile) the two waves of a row tile split the
+// channels -- one of the chunk's two 16-channel tiles each in GEMM 3, half of MIDN each in GEMM 1' -- so that the accumulators
+// fit 128 registers per lane and four waves per SIMD issue where two did (the 256-channel shapes are issue-bound, not
+// memory-bound: DESIGN.md section 4.4b).
 
 struct ChainArgs {
     const uint16_t* t2;    // [M][MID]
@@ -63,24 +67,28 @@ __device__ __forceinline__ int ec_src_chunk(int row, int slot) {   // which k-ch
     return (0x78 >> (2 * v)) & 3;                           // the inverse of H: {0, 2, 3, 1}
 }
 
-template <int MID, int MIDN, int R, bool CHAIN, int AHEAD = 2, int NW = 8>
+template <int MID, int MIDN, int R, bool CHAIN, int AHEAD = 2, int NW = 8, int NSPLIT = 1>
 __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs p) {
-    constexpr int EC_THREADS = NW * 64, ROWS = NW * 16, EC_ITEM_E = ROWS * 32;
+    constexpr int EC_THREADS = NW * 64, ROWS = NW * 16 / NSPLIT, EC_ITEM_E = ROWS * 32;
     constexpr int NL = NW / 2;              // loader waves (0 .. NL - 1); the others are the storers
+    constexpr int NJ = 2 / NSPLIT;          // GEMM 3: 16-channel tiles of the 32-channel chunk per wave
     constexpr int C4 = 4 * MID;
     constexpr int KA = MID / 32;            // A items (k-steps of t2) per tile
     constexpr int NCH = C4 / 32;            // RES items (chunks of Y) per tile
     constexpr int SPT = KA + NCH;           // steps per tile
     constexpr int WC_E = 32 * MID;          // one Wc chunk: [KA][32 rows][32]
     constexpr int WA_E = CHAIN ? MIDN * 32 : 0;   // one Wa' chunk: [MIDN rows][32]
-    constexpr int NT1 = CHAIN ? MIDN / 16 : 1;    // GEMM 1': 16-channel tiles of a storer wave (all of them)
+    constexpr int NT1 = CHAIN ? MIDN / 16 / NSPLIT : 1;   // GEMM 1': 16-channel tiles per wave
     constexpr int WC_DMA = 2 * KA / NL;     // LDS-DMA instructions per loader wave: Wc chunk (1 KB each) ...
     constexpr int WA_DMA = CHAIN ? MIDN / 16 / NL : 0;  // ... Wa' chunk ...
     constexpr int IT_DMA = (ROWS / 16) / NL;            // ... ring item
-    static_assert(2 * KA % NL == 0 && (!CHAIN || (MIDN / 16) % NL == 0) && IT_DMA == 2, "LDS-DMA split over the loader waves");
+    constexpr int PIECES = ROWS * 4 / (NL * 64);        // 16-byte pieces of a Y chunk per storer lane
+    static_assert(2 * KA % NL == 0 && (!CHAIN || (MIDN / 16) % NL == 0) && IT_DMA >= 1 && PIECES >= 1 && (NSPLIT == 1 || NW == 16), "work split over the waves");
     constexpr int NB_C = AHEAD + 1, NB_A = AHEAD + 2;   // Wc / Wa' buffers: a chunk is issued AHEAD RES steps ahead into the buffer read last one / two steps ago
     constexpr int SMEM_E = NB_C * WC_E + NB_A * WA_E + R * EC_ITEM_E + 2 * (C4 + (CHAIN ? MIDN : 0));
     static_assert(R >= 4, "an item must be older than the previous step's issue when it is consumed");
+    static_assert(AHEAD >= 2, "the wait at the end of a step leaves that step's issues in flight: the next step's weights must be older "
+                              "(AHEAD = 1 was tried for a deeper item ring: the bit-identity test caught the race at once)");
     static_assert(SMEM_E * 2 <= 160 * 1024, "LDS budget");
     static_assert(SMEM_E * 2 > 80 * 1024, "one workgroup per CU by construction: keep the LDS image above half a CU's LDS");
     __shared__ __attribute__((aligned(1024))) uint16_t smem[SMEM_E];
@@ -190,17 +198,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
 #pragma unroll
     for (int n = 0; n < NT1; n++) acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     float amax = 0.f;
-    const int my_row = wave * 16 + frag_row;       // row of the tile this lane's outputs belong to
+    const int mt = wave % (NW / NSPLIT), np_ = wave / (NW / NSPLIT);   // this wave's 16-pixel row tile, and which part of the channels
+    const int my_row = mt * 16 + frag_row;         // row of the tile this lane's outputs belong to
     // per-lane constants of the LDS accesses (element offsets inside an item / a weight buffer)
     const int a_frag_off = ec_slot(my_row, frag_q);                 // this lane's A fragment in an item (t2 k-step or Y chunk)
     const int b_frag_off = ec_slot(frag_row, frag_q);               // B fragment of a 16-row tile (+ 512 elements per tile)
-    int cell_off[2];
+    int cell_off[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; j++) cell_off[j] = ec_slot(my_row, (16 * j + 4 * frag_q) >> 3) + ((16 * j + 4 * frag_q) & 7);
-    int piece_off[2];                                               // storer lanes: two 16-byte pieces of a Y chunk
-    uint32_t piece_goff[2];                                         // ... and their byte offsets in Y relative to the tile's chunk
+    for (int j = 0; j < NJ; j++) cell_off[j] = ec_slot(my_row, (16 * (j + np_ * NJ) + 4 * frag_q) >> 3) + ((16 * (j + np_ * NJ) + 4 * frag_q) & 7);
+    int piece_off[PIECES];                                          // storer lanes: 16-byte pieces of a Y chunk
+    uint32_t piece_goff[PIECES];                                    // ... and their byte offsets in Y relative to the tile's chunk
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
+    for (int it = 0; it < PIECES; it++) {
         const int piece = it * (NL * 64) + sw * 64 + lane, row = piece >> 2, q = piece & 3;
         piece_off[it] = ec_slot(row, q);
         piece_goff[it] = (uint32_t)((row * C4 + q * 8) * 2);
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
     auto chain_prev = [&]() {
         if constexpr (CHAIN) {
             const uint16_t* Yc = Ring + prev_slot * EC_ITEM_E;
-            const uint16_t* Wn = WaB + prev_ab * WA_E + b_frag_off;
+            const uint16_t* Wn = WaB + prev_ab * WA_E + b_frag_off + np_ * NT1 * 512;
             // all fragment reads of a batch first, then its MFMAs: left to itself hipcc re-uses one register quad for every
             // B fragment and emits read -> wait -> MFMA per tile, i.e. an LDS round trip in front of every MFMA
             const act8 ay = *reinterpret_cast<const act8*>(Yc + a_frag_off);
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
                 const long long m = prev_m0 + my_row;
                 float4 bias[NT1];
 #pragma unroll
-                for (int n = 0; n < NT1; n++) bias[n] = lds_read_f4(biasa + 16 * n + 4 * frag_q);
+                for (int n = 0; n < NT1; n++) bias[n] = lds_read_f4(biasa + 16 * (n + np_ * NT1) + 4 * frag_q);
                 uint2 o[NT1];
 #pragma unroll
                 for (int n = 0; n < NT1; n++) {
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
                     acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 if (m < p.M) {
-                    uint16_t* dst = p.t1n + m * MIDN + 4 * frag_q;
+                    uint16_t* dst = p.t1n + m * MIDN + 16 * np_ * NT1 + 4 * frag_q;
 #pragma unroll
                     for (int n = 0; n < NT1; n++) *reinterpret_cast<uint2*>(dst + 16 * n) = o[n];
                 }
@@ -258,19 +267,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
         if (p.dbg & 4) return;
         const uint16_t* Yc = Ring + prev_slot * EC_ITEM_E;
         char* ybase = reinterpret_cast<char*>(p.y) + prev_m0 * (C4 * 2) + prev_nc * 64;   // wave-uniform
-        act8 vh[2];
+        act8 vh[PIECES];
 #pragma unroll
-        for (int it = 0; it < 2; it++) vh[it] = *reinterpret_cast<const act8*>(Yc + piece_off[it]);
-        asm volatile("" : "+v"(vh[0]), "+v"(vh[1]));
-        uint4 v[2];
+        for (int it = 0; it < PIECES; it++) vh[it] = *reinterpret_cast<const act8*>(Yc + piece_off[it]);
+        if constexpr (PIECES == 2) asm volatile("" : "+v"(vh[0]), "+v"(vh[1]));
+        else asm volatile("" : "+v"(vh[0]));
+        uint4 v[PIECES];
 #pragma unroll
-        for (int it = 0; it < 2; it++) v[it] = __builtin_bit_cast(uint4, vh[it]);
+        for (int it = 0; it < PIECES; it++) v[it] = __builtin_bit_cast(uint4, vh[it]);
         if (prev_m0 + ROWS <= p.M) {       // a full tile (wave-uniform): no row guards
 #pragma unroll
-            for (int it = 0; it < 2; it++) *reinterpret_cast<uint4*>(ybase + piece_goff[it]) = v[it];
+            for (int it = 0; it < PIECES; it++) *reinterpret_cast<uint4*>(ybase + piece_goff[it]) = v[it];
         } else {
 #pragma unroll
-            for (int it = 0; it < 2; it++) {
+            for (int it = 0; it < PIECES; it++) {
                 const int row = (it * (NL * 64) + sw * 64 + lane) >> 2;
                 if (prev_m0 + row < p.M) *reinterpret_cast<uint4*>(ybase + piece_goff[it]) = v[it];
             }
@@ -314,24 +324,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
                 if (!loader) store_prev();
                 chain_prev();
             }
-            const uint16_t* Wb = WcB + c_cb * WC_E + b_frag_off;
-            f32x4 acc3[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const uint16_t* Wb = WcB + c_cb * WC_E + b_frag_off + np_ * NJ * 512;
+            f32x4 acc3[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             // the epilogue's LDS reads (bias, residual cell) are issued in front of GEMM 3's: LDS returns in order, so they ride
             // under the multiply instead of costing a round trip of their own after it
-            act8 bias_h[2];                        // (raw _Float16-typed loads; laundered together below: one asm, one wait)
-            half4v rr_h[2];
+            act8 bias_h[NJ];                       // (raw _Float16-typed loads; laundered together below: one asm, one wait)
+            half4v rr_h[NJ];
             constexpr int KB = NW == 16 ? 2 : (KA < 8 ? KA : 8);   // k-steps per batch of fragment reads (16 reads = 64 VGPRs)
 #pragma unroll
             for (int k0 = 0; k0 < KA; k0 += KB) {
-                act8 bfr[KB][2];
+                act8 bfr[KB][NJ];
 #pragma unroll
                 for (int ks = 0; ks < KB; ks++)
 #pragma unroll
-                    for (int j = 0; j < 2; j++) bfr[ks][j] = *reinterpret_cast<const act8*>(Wb + (k0 + ks) * 1024 + j * 512);
+                    for (int j = 0; j < NJ; j++) bfr[ks][j] = *reinterpret_cast<const act8*>(Wb + (k0 + ks) * 1024 + j * 512);
                 if (k0 + KB >= KA) {
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        bias_h[j] = *reinterpret_cast<const act8*>(biasc + nc * 32 + 16 * j + 4 * frag_q);
+                    for (int j = 0; j < NJ; j++) {
+                        bias_h[j] = *reinterpret_cast<const act8*>(biasc + nc * 32 + 16 * (j + np_ * NJ) + 4 * frag_q);
                         rr_h[j] = *reinterpret_cast<const half4v*>(slot + cell_off[j]);
                     }
                 }
@@ -339,17 +351,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
 #pragma unroll
                 for (int ks = 0; ks < KB; ks++)
 #pragma unroll
-                    for (int j = 0; j < 2; j++) acc3[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[ks][j], afr[k0 + ks], acc3[j], 0, 0, 0);
+                    for (int j = 0; j < NJ; j++) acc3[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[ks][j], afr[k0 + ks], acc3[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // bias + residual + ReLU on the accumulator's own elements, in place in the ring slot (fp32, one rounding)
-            asm volatile("" : "+v"(bias_h[0]), "+v"(bias_h[1]), "+v"(rr_h[0]), "+v"(rr_h[1]));   // keeps the four loads <n x half>-typed (lds_read8)
-            float4 bias[2];
-            uint2 rr[2];
+            if constexpr (NJ == 2) asm volatile("" : "+v"(bias_h[0]), "+v"(bias_h[1]), "+v"(rr_h[0]), "+v"(rr_h[1]));   // keeps the loads <n x half>-typed (lds_read8)
+            else asm volatile("" : "+v"(bias_h[0]), "+v"(rr_h[0]));
+            float4 bias[NJ];
+            uint2 rr[NJ];
 #pragma unroll
-            for (int j = 0; j < 2; j++) { bias[j] = __builtin_bit_cast(float4, bias_h[j]); rr[j] = __builtin_bit_cast(uint2, rr_h[j]); }
+            for (int j = 0; j < NJ; j++) { bias[j] = __builtin_bit_cast(float4, bias_h[j]); rr[j] = __builtin_bit_cast(uint2, rr_h[j]); }
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < NJ; j++) {
                 float v0 = acc3[j][0] + bias[j].x, v1 = acc3[j][1] + bias[j].y, v2 = acc3[j][2] + bias[j].z, v3 = acc3[j][3] + bias[j].w;
                 v0 += act_to_f32((uint16_t)(rr[j].x & 0xFFFFu));
                 v1 += act_to_f32((uint16_t)(rr[j].x >> 16));

@@ -840,6 +840,7 @@ struct ResnetHandle {
     std::vector<int> chain;  // per op: 1 = this expand convolution (+ residual) runs as expand_chain_kernel, 2 = ... together with
                              //         the next op, the following block's first 1x1 convolution (expand_chain.h)
     int n_cus = 256;
+    int chain_split = 1;                  // SALVE_CHAIN_SPLIT=0: the 8-wave form for the 256-channel shapes too
     int chain_dbg = 0, chain_waves = 8;   // development: SALVE_CHAIN_DBG (timing-only ablations of expand_chain_kernel), SALVE_CHAIN_WAVES = 8 | 16
 };
 
@@ -1016,6 +1017,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
         }
         if (const char* d = getenv("SALVE_CHAIN_DBG")) h->chain_dbg = atoi(d);
         if (const char* d = getenv("SALVE_CHAIN_WAVES")) h->chain_waves = atoi(d);
+        if (const char* d = getenv("SALVE_CHAIN_SPLIT")) h->chain_split = atoi(d);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             h->n_cus = cus;
@@ -1130,11 +1132,17 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             // 1.55 ms -- but with them it takes the same 1.95 ms: at 4.1 TB/s of mixed reads and writes in 64-byte row pieces the
             // memory system is what is left.  Bit-identical; not the default.
             const bool wide = h->chain_waves == 16 && mid == 128 && (!chained || midn == 128);
+            // 16 waves with the channels split over wave pairs (128-pixel tiles) for the 256-channel shapes: they are bound by
+            // their instruction issue at two waves per SIMD (236-246 VGPRs), not by memory
+            const bool split = !wide && h->chain_split && (mid == 256 || (chained && midn == 256));
             const int rows = wide ? 256 : 128;
             a.n_tiles = (int)((M + rows - 1) / rows);
             const unsigned grid = (unsigned)(a.n_tiles < h->n_cus ? a.n_tiles : h->n_cus);   // persistent: one workgroup per CU
-            const dim3 blk(wide ? 1024 : 512);
-            if (wide && chained) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 6, true, 2, 16>), dim3(grid), blk, 0, s, a);
+            const dim3 blk((wide || split) ? 1024 : 512);
+            if (split && chained && mid == 128) hipLaunchKernelGGL((expand_chain_kernel<128, 256, 8, true, 2, 16, 2>), dim3(grid), blk, 0, s, a);
+            else if (split && chained) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 5, true, 2, 16, 2>), dim3(grid), blk, 0, s, a);
+            else if (split) hipLaunchKernelGGL((expand_chain_kernel<256, 256, 12, false, 2, 16, 2>), dim3(grid), blk, 0, s, a);
+            else if (wide && chained) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 6, true, 2, 16>), dim3(grid), blk, 0, s, a);
             else if (wide) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 7, false, 2, 16>), dim3(grid), blk, 0, s, a);
             else if (chained && mid == 128 && midn == 128) hipLaunchKernelGGL((expand_chain_kernel<128, 128, 12, true>), dim3(grid), blk, 0, s, a);
             else if (chained && mid == 128 && midn == 256) hipLaunchKernelGGL((expand_chain_kernel<128, 256, 8, true>), dim3(grid), blk, 0, s, a);

@@ -238,9 +238,10 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(monke
     x = torch.randn(batch, 224, 224, cin).to(torch.float16).to(DEV)
     x[..., (6 if layers == 50 else 12):] = 0
     outs = {}
-    for mode in ("0", "1", "2", "2w"):
+    for mode in ("0", "1", "2", "2w", "2n", "1n"):
         monkeypatch.setenv("SALVE_RESNET_CHAIN", mode[0])   # read when the handle is created
         monkeypatch.setenv("SALVE_CHAIN_WAVES", "16" if mode.endswith("w") else "8")   # "2w": the 16-wave / 256-pixel-tile variant
+        monkeypatch.setenv("SALVE_CHAIN_SPLIT", "0" if mode.endswith("n") else "1")    # "n": no channel split (8 waves) for the 256-channel shapes
         eng = hip_resnet.HipResNet(model.state_dict(), layers, torch.device(DEV))
         for rep in range(3):                             # a misplaced wait in a ring shows up as a rare wrong tile: repeat
             o = eng.forward_nhwc(x).clone()
@@ -253,6 +254,7 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(monke
     assert torch.equal(outs["1"], outs["0"]), "expand-only kernel differs from the implicit-GEMM path"
     assert torch.equal(outs["2"], outs["0"]), "chained kernel differs from the implicit-GEMM path"
     assert torch.equal(outs["2w"], outs["0"]), "16-wave chained kernel differs from the implicit-GEMM path"
+    assert torch.equal(outs["2n"], outs["0"]) and torch.equal(outs["1n"], outs["0"]), "8-wave form of the 256-channel shapes differs"
 
 
 def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool(monkeypatch):
