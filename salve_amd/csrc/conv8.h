@@ -263,6 +263,8 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
         __syncthreads();
     }
     float amax = 0.f;
+    float amin = 0.f;
+    const float lo = p.relu ? 0.f : -65504.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int ncol = wc * 64 + j * 16 + 4 * frag_q;  // this lane's 4 consecutive channels of tile column j
@@ -271,24 +273,12 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
         for (int i = 0; i < 8; i++) {
             const int mrow = wr * 128 + i * 16 + frag_row;
             uint2* cell = reinterpret_cast<uint2*>(Cs + mrow * LDC + ncol);
-            float v0 = acc[i][j][0] + bias.x, v1 = acc[i][j][1] + bias.y, v2 = acc[i][j][2] + bias.z, v3 = acc[i][j][3] + bias.w;
-            if (p.res) {
-                const uint2 r = *cell;
-                v0 += act_to_f32((uint16_t)(r.x & 0xFFFFu));
-                v1 += act_to_f32((uint16_t)(r.x >> 16));
-                v2 += act_to_f32((uint16_t)(r.y & 0xFFFFu));
-                v3 += act_to_f32((uint16_t)(r.y >> 16));
-            }
-            if (p.relu) {
-                v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-            }
-            track4(amax, v0, v1, v2, v3);
-            uint2 o;
-            o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
-            o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
-            *cell = o;
+            f32x4 v = acc[i][j] + vec4(bias);
+            if (p.res) v += vec4(*cell);
+            *cell = pack4_lo(amax, amin, v, lo);
         }
     }
+    if (!p.relu) amax = fmaxf(amax, -amin);
     report_range(p.status, amax);
     __syncthreads();
 #pragma unroll 4

@@ -248,11 +248,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
                 uint2 o[NT1];
 #pragma unroll
                 for (int n = 0; n < NT1; n++) {
-                    const float v0 = fmaxf(acc1[n][0] + bias[n].x, 0.f), v1 = fmaxf(acc1[n][1] + bias[n].y, 0.f);
-                    const float v2 = fmaxf(acc1[n][2] + bias[n].z, 0.f), v3 = fmaxf(acc1[n][3] + bias[n].w, 0.f);
-                    track4(amax, v0, v1, v2, v3);
-                    o[n].x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
-                    o[n].y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
+                    o[n] = pack4<true>(amax, acc1[n] + vec4(bias[n]));
                     acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 if (m < p.M) {
@@ -363,17 +359,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
             for (int j = 0; j < NJ; j++) { bias[j] = __builtin_bit_cast(float4, bias_h[j]); rr[j] = __builtin_bit_cast(uint2, rr_h[j]); }
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
-                float v0 = acc3[j][0] + bias[j].x, v1 = acc3[j][1] + bias[j].y, v2 = acc3[j][2] + bias[j].z, v3 = acc3[j][3] + bias[j].w;
-                v0 += act_to_f32((uint16_t)(rr[j].x & 0xFFFFu));
-                v1 += act_to_f32((uint16_t)(rr[j].x >> 16));
-                v2 += act_to_f32((uint16_t)(rr[j].y & 0xFFFFu));
-                v3 += act_to_f32((uint16_t)(rr[j].y >> 16));
-                v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                amax = fmaxf(fmaxf(amax, v0), fmaxf(v1, fmaxf(v2, v3)));   // (after the ReLU: no |.| needed)
-                uint2 o;
-                o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
-                o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
-                lds_write8(slot + cell_off[j], o);
+                lds_write8(slot + cell_off[j], pack4<true>(amax, acc3[j] + vec4(bias[j]) + vec4(rr[j])));
             }
             if (loader) {   // the NEXT step's data has landed: everything but what this step's issue put in flight
                 if (tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

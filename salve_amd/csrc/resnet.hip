@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/salve_hip.h"
@@ -93,6 +94,51 @@ __device__ __forceinline__ uint16_t f32_to_act(float f) {
 __device__ __forceinline__ void track4(float& amax, float v0, float v1, float v2, float v3) {
     amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
     amax = fmaxf(amax, fmaxf(fabsf(v2), fabsf(v3)));
+}
+// The epilogue arithmetic of every convolution kernel: four fp32 sums (accumulator + bias [+ residual]) -> [ReLU] -> saturate ->
+// fp16, two per dword.  RELU: v_max3 (range tracking; negative sums cannot raise a maximum that starts at 0 and the ReLU stores
+// 0 for them) + 2 v_med3 (ReLU and saturation in one: the median of x, 0, 65504) + v_cvt_pk_f16_f32 per PAIR -- 2 instructions
+// per value where fmaxf / fminf / two conversions / or took 5 (round 3: the fused 56x56 block issued 1250 vector instructions
+// per wave and tile next to its 152 MFMAs).  Same values as f32_to_act(fmaxf(v, 0)): one rounding, to nearest even; a NaN sum
+// stores 0 (-65504 without ReLU), as before.
+template <bool RELU>
+__device__ __forceinline__ uint32_t pack2(float& amax, float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    constexpr float lo = RELU ? 0.f : -65504.f;
+    amax = RELU ? fmaxf(amax, fmaxf(a, b)) : fmaxf(amax, fmaxf(fabsf(a), fabsf(b)));
+    const f2 v = {__builtin_amdgcn_fmed3f(a, lo, 65504.f), __builtin_amdgcn_fmed3f(b, lo, 65504.f)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2));
+}
+template <bool RELU>
+__device__ __forceinline__ uint2 pack4(float& amax, f32x4 v) {
+    uint2 o;
+    o.x = pack2<RELU>(amax, v[0], v[1]);
+    o.y = pack2<RELU>(amax, v[2], v[3]);
+    return o;
+}
+// The same for the general kernels, whose ReLU is a launch argument: `lo` = 0 (ReLU) or -65504, the low side of the range tracked
+// as a minimum of its own (half an instruction more per value) -- ONE code path: two copies of the epilogue under a branch made
+// hipcc spill in conv8_kernel, whose 128 accumulator registers are live there.  Report fmaxf(amax, relu ? 0 : -amin).
+__device__ __forceinline__ uint2 pack4_lo(float& amax, float& amin, f32x4 v, float lo) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    amax = fmaxf(amax, fmaxf(v[0], v[1]));
+    amax = fmaxf(amax, fmaxf(v[2], v[3]));
+    amin = fminf(amin, fminf(v[0], v[1]));
+    amin = fminf(amin, fminf(v[2], v[3]));
+    const f2 a = {__builtin_amdgcn_fmed3f(v[0], lo, 65504.f), __builtin_amdgcn_fmed3f(v[1], lo, 65504.f)};
+    const f2 b = {__builtin_amdgcn_fmed3f(v[2], lo, 65504.f), __builtin_amdgcn_fmed3f(v[3], lo, 65504.f)};
+    uint2 o;
+    o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, h2));
+    o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, h2));
+    return o;
+}
+// The sums as vector expressions, so that they become v_pk_add_f32 (two fp32 additions per instruction; same IEEE results).
+__device__ __forceinline__ f32x4 vec4(float4 b) { return f32x4{b.x, b.y, b.z, b.w}; }
+__device__ __forceinline__ f32x4 vec4(uint2 r) {   // four fp16 residual values
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    return __builtin_convertvector(__builtin_bit_cast(h4, r), f32x4);
 }
 __device__ __forceinline__ void report_range(int32_t* status, float amax) {
     if (status && !(amax <= 65504.f)) atomicOr(status, SALVE_STATUS_FP16_RANGE);
@@ -272,6 +318,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
         __syncthreads();
     }
     float amax = 0.f;
+    float amin = 0.f;
+    const float lo = p.relu ? 0.f : -65504.f;
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         const int ncol = wc * WN + j * 16 + 4 * (lane >> 4);  // this lane's 4 consecutive channels of tile column j
@@ -280,24 +328,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
         for (int i = 0; i < 4; i++) {
             const int mrow = wr * 64 + i * 16 + (lane & 15);
             uint2* cell = reinterpret_cast<uint2*>(Cs + mrow * LDC + ncol);
-            float v0 = acc[i][j][0] + bias.x, v1 = acc[i][j][1] + bias.y, v2 = acc[i][j][2] + bias.z, v3 = acc[i][j][3] + bias.w;
-            if (p.res) {
-                const uint2 r = *cell;
-                v0 += act_to_f32((uint16_t)(r.x & 0xFFFFu));
-                v1 += act_to_f32((uint16_t)(r.x >> 16));
-                v2 += act_to_f32((uint16_t)(r.y & 0xFFFFu));
-                v3 += act_to_f32((uint16_t)(r.y >> 16));
-            }
-            if (p.relu) {
-                v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-            }
-            track4(amax, v0, v1, v2, v3);
-            uint2 o;
-            o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
-            o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
-            *cell = o;
+            f32x4 v = acc[i][j] + vec4(bias);
+            if (p.res) v += vec4(*cell);
+            *cell = pack4_lo(amax, amin, v, lo);
         }
     }
+
+    if (!p.relu) amax = fmaxf(amax, -amin);
     report_range(p.status, amax);
     __syncthreads();
 #pragma unroll
@@ -535,6 +572,8 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             for (int j = 0; j < NT1; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr int NK1 = CIN / 64;
         ISSUE_A(0);
+        // (Round 3: touching the later k-tiles' lines up front -- one 4-byte LDS-DMA lane per 128-byte line into scratch LDS, so
+        // that the stages after the first hit the L2 -- measured +1 % on the forward: the phases are not waiting for those lines.)
 #pragma unroll
         for (int kt = 0; kt < NK1; kt++) {
             // the next tile goes into the other buffer (last read one iteration ago, behind a barrier) and stays in
@@ -584,17 +623,14 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             const int h = (wm * MT1 + i) * 16 + frag_row;
             const int hy = oy0 - 1 + h / HC, hx = ox0 - 1 + h % HC;
             const bool inside = h < HALO && hy >= 0 && hy < p.H && hx >= 0 && hx < p.W;
+            const uint32_t keep = inside ? 0xFFFFFFFFu : 0u;   // (a mask, not a select around the conversions: hipcc made branches of those)
             const int swz = MID == 64 ? ((h >> 1) & 7) : (h & 15);
 #pragma unroll
             for (int j = 0; j < NT1; j++) {
                 const int c0 = (wn * NT1 + j) * 16 + 4 * frag_q;
                 const float4 bias = *reinterpret_cast<const float4*>(p.ba + c0);
-                float v0 = fmaxf(acc[i][j][0] + bias.x, 0.f), v1 = fmaxf(acc[i][j][1] + bias.y, 0.f);
-                float v2 = fmaxf(acc[i][j][2] + bias.z, 0.f), v3 = fmaxf(acc[i][j][3] + bias.w, 0.f);
-                track4(amax, v0, v1, v2, v3);
-                uint2 o;
-                o.x = inside ? ((uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16)) : 0u;
-                o.y = inside ? ((uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16)) : 0u;
+                uint2 o = pack4<true>(amax, acc[i][j] + vec4(bias));
+                o.x &= keep; o.y &= keep;
                 *reinterpret_cast<uint2*>(T1 + h * MID + (((c0 >> 3) ^ swz) << 3) + (c0 & 7)) = o;
             }
         }
@@ -654,13 +690,8 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             for (int j = 0; j < NT2; j++) {
                 const int c0 = (wc * NT2 + j) * 16 + 4 * frag_q;
                 const float4 bias = *reinterpret_cast<const float4*>(p.bb + c0);
-                const float v0 = fmaxf(acc[i][j][0] + bias.x, 0.f), v1 = fmaxf(acc[i][j][1] + bias.y, 0.f);
-                const float v2 = fmaxf(acc[i][j][2] + bias.z, 0.f), v3 = fmaxf(acc[i][j][3] + bias.w, 0.f);
-                track4(amax, v0, v1, v2, v3);
-                uint2 o;
-                o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
-                o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
-                *reinterpret_cast<uint2*>(T2 + m * MID + (((c0 >> 3) ^ swz) << 3) + (c0 & 7)) = o;
+                *reinterpret_cast<uint2*>(T2 + m * MID + (((c0 >> 3) ^ swz) << 3) + (c0 & 7)) =
+                    pack4<true>(amax, acc[i][j] + vec4(bias));
             }
         }
     }
@@ -722,13 +753,8 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
 #pragma unroll
                 for (int i = 0; i < RT; i++) {
                     const int m = (wr * RT + i) * 16 + frag_row;
-                    const float v0 = fmaxf(acc[i][j][0] + bias.x, 0.f), v1 = fmaxf(acc[i][j][1] + bias.y, 0.f);
-                    const float v2 = fmaxf(acc[i][j][2] + bias.z, 0.f), v3 = fmaxf(acc[i][j][3] + bias.w, 0.f);
-                    track4(amax, v0, v1, v2, v3);
-                    uint2 o;
-                    o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
-                    o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
-                    *reinterpret_cast<uint2*>(Cp + m * LDC_P + ncol) = o;
+                    *reinterpret_cast<uint2*>(Cp + m * LDC_P + ncol) =
+                        pack4<true>(amax, acc[i][j] + vec4(bias));
                 }
             }
             __syncthreads();
@@ -795,15 +821,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                     const int m = (wr * RT + i) * 16 + frag_row;
                     uint2* cell = reinterpret_cast<uint2*>(Cs + m * LDC + ncol);
                     const uint2 r = resid[nc][i][j];   // (a pixel beyond the image's right edge holds zeros: its halo row was the zero page)
-                    const float v0 = fmaxf(acc[i][j][0] + bias.x + act_to_f32((uint16_t)(r.x & 0xFFFFu)), 0.f);
-                    const float v1 = fmaxf(acc[i][j][1] + bias.y + act_to_f32((uint16_t)(r.x >> 16)), 0.f);
-                    const float v2 = fmaxf(acc[i][j][2] + bias.z + act_to_f32((uint16_t)(r.y & 0xFFFFu)), 0.f);
-                    const float v3 = fmaxf(acc[i][j][3] + bias.w + act_to_f32((uint16_t)(r.y >> 16)), 0.f);
-                    track4(amax, v0, v1, v2, v3);
-                    uint2 o;
-                    o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
-                    o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
-                    *cell = o;
+                    *cell = pack4<true>(amax, acc[i][j] + vec4(bias) + vec4(r));
                 }
             }
             __syncthreads();
@@ -866,6 +884,7 @@ static int choose_wide(const salve_resnet_op_t& o, int force) {
     if (force == WIDE_8PHASE || force == WIDE_AUTO) {
         const bool fits = o.Cout % 256 == 0 && is_pow2(o.Cin) && o.Cin >= 64 && (o.in2_buf == SALVE_NO_BUF || o.Cin2 % 64 == 0);
         // by default only where the convolution is compute-bound (measured per shape): k >= 512
+        // K = 384 (layer 2's projection pair) measured the same on either kernel (r3)
         return (fits && (force == WIDE_8PHASE || K >= 512)) ? WIDE_8PHASE : WIDE_OFF;
     }
     if (force == WIDE_256_K64_S2) return o.Cout % 256 == 0 ? force : WIDE_OFF;

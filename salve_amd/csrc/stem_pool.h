@@ -135,12 +135,7 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int n = j * 16 + 4 * frag_q;
-                const float v0 = fmaxf(acc[i][j][0] + bias[j].x, 0.f), v1 = fmaxf(acc[i][j][1] + bias[j].y, 0.f);
-                const float v2 = fmaxf(acc[i][j][2] + bias[j].z, 0.f), v3 = fmaxf(acc[i][j][3] + bias[j].w, 0.f);
-                track4(amax, v0, v1, v2, v3);
-                uint2 o;
-                o.x = (uint32_t)f32_to_act(v0) | ((uint32_t)f32_to_act(v1) << 16);
-                o.y = (uint32_t)f32_to_act(v2) | ((uint32_t)f32_to_act(v3) << 16);
+                const uint2 o = pack4<true>(amax, acc[i][j] + vec4(bias[j]));
                 // the 16-byte chunks of a pixel's 128-byte row are rotated by the pixel's column: the 16 lanes of a store
                 // group (16 consecutive pixels, same channels) would otherwise all hit one bank
                 *reinterpret_cast<uint2*>(px_row + ((((n >> 3) ^ rot) << 3) | (n & 7))) = o;
