@@ -56,15 +56,23 @@ SD_FN int sd_cache_slot(unsigned long long key) {
     return (int)((h * (unsigned long long)SD_CACHE_SIZE) >> 32);
 }
 
-// apex on the left of u -> v, if some walk has already resolved that triangle
-SD_FN bool sd_cache_lookup(const SdGrid& g, int ux, int uy, int vx, int vy, int* px, int* py) {
-    if (g.cache == nullptr) return false;
+// apex on the left of u -> v, if some walk has already resolved that triangle: 1 = found, 2 = u -> v is known to be a hull edge
+// (nothing on its left: bit 63 of the entry; every hull edge is asked for twice, once from either end), 0 = not in the cache
+#define SD_CACHE_HULL (1ull << 63)
+SD_FN int sd_cache_lookup(const SdGrid& g, int ux, int uy, int vx, int vy, int* px, int* py) {
+    if (g.cache == nullptr) return 0;
     const unsigned long long key = sd_cache_key(ux, uy, vx, vy);
     const unsigned long long e = g.cache[sd_cache_slot(key)];
-    if ((e >> 20) != key || e == 0ull) return false;
+    if (((e & ~SD_CACHE_HULL) >> 20) != key || e == 0ull) return 0;
+    if (e & SD_CACHE_HULL) return 2;
     *px = (int)(e & 1023u);
     *py = (int)((e >> 10) & 1023u);
-    return true;
+    return 1;
+}
+SD_FN void sd_cache_insert_hull(const SdGrid& g, int ux, int uy, int vx, int vy) {
+    if (g.cache == nullptr || g.lane != 0) return;
+    const unsigned long long k0 = sd_cache_key(ux, uy, vx, vy);
+    g.cache[sd_cache_slot(k0)] = (k0 << 20) | SD_CACHE_HULL;
 }
 
 // triangle (u, v, p), counter-clockwise: three directed edges, each with the third vertex on its left.  One lane
@@ -472,9 +480,12 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     if (sd_side_is_empty(g, sx, sy, ax, ay, dir)) return false;
     // the side `dir` of s -> a is the left of (u -> v) = (s -> a) or (a -> s)
     const int ux = dir > 0 ? sx : ax, uy = dir > 0 ? sy : ay, vx = dir > 0 ? ax : sx, vy = dir > 0 ? ay : sy;
-    if (sd_cache_lookup(g, ux, uy, vx, vy, outx, outy)) {
-        SD_COUNT(apex_cached);
-        return true;
+    {
+        const int hit = sd_cache_lookup(g, ux, uy, vx, vy, outx, outy);
+        if (hit) {
+            SD_COUNT(apex_cached);
+            return hit == 1;
+        }
     }
     const SdEdge edge = sd_edge(sx, sy, ax, ay, dir);
     SdBest best;
@@ -506,6 +517,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         if (best.px >= 0) break;
         if (wy0 <= g.by0 && wx0 <= g.bx0 && wy1 >= g.by1 && wx1 >= g.bx1) {
             SD_LAP(far, lap);
+            sd_cache_insert_hull(g, ux, uy, vx, vy);
             return false;
         }
         SD_COUNT(apex_far);

@@ -26,7 +26,7 @@ bev, dbg = ras.render(d_rgb, d_depth, hd, n, debug=True)
 torch.cuda.synchronize()
 st = dbg.stats.cpu().numpy().astype(np.float64)
 names = ["apex", "apex_slow", "apex_far", "rows", "bits", "exact", "apex_table", "apex_cached"]
-print({k: round(v, 1) for k, v in zip(names, st.mean(0))})
+print({k: round(v / (1 if k in ("rows", "bits") else 64), 1) for k, v in zip(names, st.mean(0))}, "(per render; queries are counted by all 64 lanes: / 64; rows and bits are lane counts)")
 ras.cfg.reserved1 = 64
 bev, dbg = ras.render(d_rgb, d_depth, hd, n, debug=True)
 torch.cuda.synchronize()
