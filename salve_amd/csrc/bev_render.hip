@@ -399,7 +399,9 @@ struct QueueEmit {
     RasterEmit fallback;
     int* counter_mid;  // LDS: midpoint triangles, [capacity, 2 capacity)
     int* counter_cen;  // LDS: centroid triangles, [2 capacity, 3 capacity)
+    bool drop;         // development (dbg_flags & 1024): timing only, nothing is queued
     __device__ __forceinline__ void operator()(int ax, int ay, int bx, int by, int cx, int cy) const {
+        if (drop) return;
         // most triangles of a densely covered region are unit lattice triangles (twice the area = 1): no lattice point
         // other than the vertices lies in them (Pick), nothing to interpolate
         const int32_t area = sd_orient(ax, ay, bx, by, cx, cy);
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     if (!degenerate && !(c.dbg_flags & 1)) {
         SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13], (H <= 1024 && W <= 1024 && !(c.dbg_flags & 256)) ? tri_cache : nullptr};
         RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (c.dbg_flags & 2) != 0};
-        QueueEmit qemit = {triq, &scal[8], (H * W) / 3, raster, &scal[15], &scal[16]};
+        QueueEmit qemit = {triq, &scal[8], (H * W) / 3, raster, &scal[15], &scal[16], (c.dbg_flags & 1024) != 0};
         const int hard_cap = (H * W) >> 1;   // entries of two words: the site, and where its lean walk stood
         SdLean st;
         bool active = false, exhausted = false;

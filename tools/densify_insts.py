@@ -7,7 +7,7 @@ With a directory argument it prints the counters per launch instead (report mode
 import sys
 from pathlib import Path
 FLAGS = (("whole kernel", 0), ("E2 walks, no rasterisation inside", 2), ("no general walk (E2)", 4), ("no triangle rasterisation (F)", 8),
-         ("no E2, no F", 12), ("no star walk at all (B, B2, C, G only)", 1))
+         ("no E2, no F", 12), ("no E2, no F, lean walks queue nothing", 12 | 1024), ("no star walk at all (B, B2, C, G only)", 1))
 if sys.argv[1] == "--report":
     import csv, glob, collections
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
