@@ -396,10 +396,14 @@ struct QueueEmit {
     unsigned long long* queue;
     int* counter;  // LDS: general triangles, [0, capacity)
     int capacity;  // of each third
-    RasterEmit fallback;
     int* counter_mid;  // LDS: midpoint triangles, [capacity, 2 capacity)
     int* counter_cen;  // LDS: centroid triangles, [2 capacity, 3 capacity)
     bool drop;         // development (dbg_flags & 1024): timing only, nothing is queued
+    // A queue that is full (white noise at 50 % occupancy: 97 k midpoint triangles against 83 k entries; no texture map comes
+    // near) drops the triangle and raises this flag: the caller hands the SITE to the general walk, which walks its star again
+    // and rasterises in place -- rasterising a triangle twice is harmless.  (Until round 3 the triangle was rasterised right
+    // here: three inlined copies of RasterEmit in the lean loop, 2500 vector instructions of loop body for a path no render takes.)
+    mutable bool full;
     __device__ __forceinline__ void operator()(int ax, int ay, int bx, int by, int cx, int cy) const {
         if (drop) return;
         // most triangles of a densely covered region are unit lattice triangles (twice the area = 1): no lattice point
@@ -416,7 +420,7 @@ struct QueueEmit {
                 const uint32_t half = (uint32_t)((qx - mx) & 0xFF) | ((uint32_t)((qy - my) & 0xFF) << 8);
                 store_wb(queue + capacity + slot, ((unsigned long long)half << 32) | ((uint32_t)my << 16) | (uint32_t)mx);
             } else {
-                fallback(ax, ay, bx, by, cx, cy);
+                full = true;
             }
             return;
         }
@@ -430,7 +434,7 @@ struct QueueEmit {
                                      ((uint32_t)((bx - mx) & 0xFF) << 16) | ((uint32_t)((by - my) & 0xFF) << 24);
                 store_wb(queue + 2 * capacity + slot, ((unsigned long long)rel << 32) | ((uint32_t)my << 16) | (uint32_t)mx);
             } else {
-                fallback(ax, ay, bx, by, cx, cy);
+                full = true;
             }
             return;
         }
@@ -440,7 +444,7 @@ struct QueueEmit {
                                  ((uint32_t)((cx - ax) & 0xFF) << 16) | ((uint32_t)((cy - ay) & 0xFF) << 24);
             store_wb(queue + slot, ((unsigned long long)rel << 32) | ((uint32_t)ay << 16) | (uint32_t)ax);
         } else {
-            fallback(ax, ay, bx, by, cx, cy);  // queue full (cannot happen below ~50 % occupancy): rasterise in place
+            full = true;
         }
     }
 };
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     if (!degenerate && !(c.dbg_flags & 1)) {
         SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13], (H <= 1024 && W <= 1024 && !(c.dbg_flags & 256)) ? tri_cache : nullptr};
         RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (c.dbg_flags & 2) != 0};
-        QueueEmit qemit = {triq, &scal[8], (H * W) / 3, raster, &scal[15], &scal[16], (c.dbg_flags & 1024) != 0};
+        QueueEmit qemit = {triq, &scal[8], (H * W) / 3, &scal[15], &scal[16], (c.dbg_flags & 1024) != 0, false};
         const int hard_cap = (H * W) >> 1;   // entries of two words: the site, and where its lean walk stood
         SdLean st;
         bool active = false, exhausted = false;
@@ -733,8 +737,14 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                 break;  // every lane is exhausted and idle
             }
             if (active) {
-                const int r = sdl_lean_step(st, g, qemit);
+                int r = sdl_lean_step(st, g, qemit);
                 iters++;
+                if (qemit.full) {   // a triangle of this site found its queue full: the general walk takes the whole site
+                    qemit.full = false;
+                    active = false;
+                    push_hard(hardlist, &scal[7], hard_cap, ((uint32_t)st.sy << 16) | (uint32_t)st.sx, HARD_FRESH, status);
+                    r = SDL_LEAN_CONTINUE;
+                }
                 if (r != SDL_LEAN_CONTINUE) {
                     active = false;
                     if (dbg_mask && (c.dbg_flags & 16))  // development: how each site's lean walk ended

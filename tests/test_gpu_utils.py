@@ -65,6 +65,20 @@ def test_interp_dense_grid_from_sparse():
         assert np.array_equal(got, bo.interp_exact(pts, colr.astype(np.uint8), G, G)[0])
 
 
+def test_interp_of_a_half_occupied_image():
+    """A 501 x 501 image with every second pixel a site (white noise): 97 k triangles of twice-the-area 2 against a midpoint
+    queue of 83 k entries (bev_render.hip: QueueEmit) -- the queue-full path, which no render of a texture map reaches.  Also
+    35 % occupancy: the general-triangle queue at 73 % of its capacity."""
+    G = 501
+    rng = np.random.default_rng(3)
+    for occ in (0.5, 0.35):
+        ys, xs = np.nonzero(rng.random((G, G)) < occ)
+        pts = np.stack([xs, ys], 1)
+        colr = rng.integers(0, 256, size=(pts.shape[0], 3)).astype(np.float64)
+        got = iu.interp_dense_grid_from_sparse(np.zeros((G, G, 3), dtype=np.uint8), pts, colr, G, G, False)
+        assert np.array_equal(got, bo.interp_exact(pts, colr.astype(np.uint8), G, G)[0]), occ
+
+
 def test_config5_large_panos_two_surfaces_resnet152():
     """2048x1024 panoramas, floor + ceiling, ResNet-152 12-channel early fusion (BASELINE config 5, fp16)."""
     from salve_amd.models.early_fusion import EarlyFusionCEResnet

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3e2
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
-timeout -k 10 600 python -m pytest tests/test_gpu_rasteriser.py tests/test_gpu_fullsize.py -m gpu -q -x > "$OUT/tests.log" 2>&1 || { tail -30 "$OUT/tests.log"; exit 1; }
+timeout -k 10 600 python -m pytest tests/test_gpu_rasteriser.py tests/test_gpu_fullsize.py tests/test_gpu_utils.py -m gpu -q -x > "$OUT/tests.log" 2>&1 || { tail -30 "$OUT/tests.log"; exit 1; }
 tail -1 "$OUT/tests.log"
 timeout -k 10 300 python tools/profile_walk.py > "$OUT/walk.log" 2>&1 || { tail -20 "$OUT/walk.log"; exit 1; }
 grep -v amdgpu "$OUT/walk.log" | cut -c1-700
