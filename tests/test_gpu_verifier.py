@@ -202,6 +202,41 @@ def test_conv_with_projection_shortcut_as_second_source(stride, hw, cx, mid, cou
     assert (err <= 3e-3 * ref.abs().clamp(min=0.5)).all(), f"max err {err.max()}"
 
 
+@pytest.mark.parametrize("K,Cout", [(64, 64), (1024, 256)])   # conv_igemm_kernel; conv8_kernel (forced)
+def test_convolution_without_relu_saturates_and_reports_both_signs(K, Cout, monkeypatch):
+    """The general convolution kernels take their ReLU as a launch argument: without it the stored value saturates at
+    +-65504 and EITHER side raises SALVE_STATUS_FP16_RANGE (the low side is tracked as a minimum of its own, resnet.hip:
+    pack4_lo); with it a hugely negative sum stores 0 and raises nothing."""
+    monkeypatch.setenv("SALVE_CONV_WIDE", "8" if K >= 512 else "0")
+    lib = _lib.load()
+    B, hw = 2, 32
+    x = torch.ones(B, hw, hw, K, dtype=torch.float16)
+    for sign, relu, expect_flag, expect_val in ((-1.0, False, True, -65504.0), (1.0, False, True, 65504.0), (-1.0, True, False, 0.0), (1.0, True, True, 65504.0)):
+        w = torch.full((Cout, K, 1, 1), sign * 256.0 / K)      # every output = sign * 256 + bias
+        b = torch.full((Cout,), sign * 1.0e5)
+        bld = hip_resnet._Builder()
+        Ho, Wo = bld.conv(w, b, hip_resnet.NET_INPUT, 0, hip_resnet.NO_BUF, hw, hw, 1, 0, relu)
+        ops = np.array(bld.ops, dtype=hip_resnet.OP_DTYPE)
+        wts, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
+        h = ctypes.c_void_p(lib.salve_resnet_create(0, K, ops.ctypes.data_as(ctypes.c_void_p), len(ops), wts.ctypes.data_as(ctypes.c_void_p), wts.nbytes,
+                                                     pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
+        assert h
+        need = lib.salve_resnet_workspace_bytes(h, B)
+        ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
+        xd = x.to(DEV)
+        word = torch.zeros(1, dtype=torch.int32, device=DEV)
+        logits = torch.zeros((B, 2), dtype=torch.float32, device=DEV)   # (unused: the program has no classifier op)
+        st = lib.salve_resnet_forward(h, ctypes.c_void_p(xd.data_ptr()), B, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                      ctypes.c_void_p(word.data_ptr()), None)
+        torch.cuda.synchronize()
+        assert st == 0, lib.salve_last_error()
+        view = ws[(-ws.data_ptr()) % 256:].view(torch.float16)
+        got = view[: B * Ho * Wo * Cout].float().cpu()
+        lib.salve_resnet_destroy(h)
+        assert (got == expect_val).all(), (sign, relu, got.unique())
+        assert bool(int(word.item()) & _lib.STATUS_FP16_RANGE) == expect_flag, (sign, relu, int(word.item()))
+
+
 def test_fused_bottleneck_is_bit_identical_to_three_kernels(monkeypatch):
     """The fused bottleneck kernel (resnet.hip: bottleneck_kernel) keeps t1 / t2 in LDS but rounds them to fp16 and
     accumulates in the same k order as the three separate convolutions: the logits must agree bit for bit."""
