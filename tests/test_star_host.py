@@ -125,15 +125,16 @@ def left_out(lib, pts, H, W):
 
 
 def test_sites_left_out_of_the_list_own_unit_triangles_only(lib):
-    """star_local.h sdl_walk_word: a site between five site neighbours is not walked by the kernel.  Every triangle such a
-    site owns must be a unit triangle (nothing to rasterise) -- on dense random sets, full lattices, image borders (the
-    bitmap word boundaries at x = 31 / 32 / 63 / 64 included) and a real render's sites."""
+    """star_local.h sdl_walk_word: a site whose left, right and upper neighbours are sites is not walked by the kernel (until
+    round 3: five neighbours).  Every triangle such a site owns must be a unit triangle (nothing to rasterise) -- on random sets
+    from half to nearly full occupancy, full lattices, image borders (the bitmap word boundaries at x = 31 / 32 / 63 / 64
+    included) and a real render's sites."""
     lib.star_host_use_table(1)
     rng = np.random.default_rng(23)
     seen = 0
     for _ in range(120):
         G = int(rng.integers(8, 100))
-        dens = rng.uniform(0.5, 0.98)
+        dens = rng.uniform(0.3, 0.98)
         pts = np.argwhere(rng.random((G, G)) < dens)[:, ::-1].copy()
         if len(pts) < 4 or bo._is_degenerate(pts):
             continue
@@ -153,4 +154,5 @@ def test_sites_left_out_of_the_list_own_unit_triangles_only(lib):
     _, img_xy = bo.bev_pixel_indices(a[:, :3])
     sites = np.unique(img_xy, axis=0)
     bad, n_out, _ = left_out(lib, sites, 501, 501)
-    assert bad == 0 and n_out > 0.3 * len(sites)
+    print(f"real render: {n_out} of {len(sites)} sites need no walk ({100.0 * n_out / len(sites):.1f} %)")
+    assert bad == 0 and n_out > 0.45 * len(sites)
