@@ -383,68 +383,33 @@ __device__ __forceinline__ void push_hard(uint32_t* list, int* counter, int cap,
     }
 }
 
-// Emit functor of the local star walk: owned triangles go to a per-render queue (8 bytes each: the site, and the two
-// other vertices relative to it) and are rasterised afterwards by all lanes at once.
+// Emit functor of the local star walk: an owned triangle that has anything to fill (twice its area > 1: a unit lattice
+// triangle holds no lattice point besides its vertices, Pick) goes to the render's queue, 8 bytes: the site and the two other
+// vertices relative to it; all lanes rasterise the queue afterwards (phase F).
 //
-// Three queues in one array.  Of the triangles that have anything to fill, two in three have twice-the-area 2: by Pick they
-// hold exactly one lattice point besides their vertices, the MIDPOINT of their one edge with an even difference vector, and
-// its colour is the floor of the mean of that edge's end points (barycentric weights 1 : 1 : 0 over 2).  Those go to the
-// second third of the array as (midpoint, half edge vector) and are filled by a loop of a dozen instructions per lane; in
-// one list with the general triangles every wavefront would run at the pace of its general ones.  Another fifth has
-// twice-the-area 3 and one interior point, its centroid (third queue).
+// ONE queue, ONE path here (round 3).  Rounds 1-2 sorted the triangles into three queues in this functor -- midpoint triangles
+// (twice-the-area 2), centroid triangles (3, lattice centroid), general ones -- so that phase F could run each kind with a loop
+// of its own; but the lean loop executes the sum of all paths any of its 64 lanes takes, and the sorting was a quarter of its
+// instructions (161 k of 611 k per render).  Phase F sorts now, where an entry is seen once by one lane.
+// The queue cannot overflow: every triangle in it holds a lattice point that is not a site (inside: in no other triangle; on
+// an edge: in one other), so there are at most 2 (H W - n) of them, and at most 2 n triangles in all: <= H W, the queue's size.
 struct QueueEmit {
     unsigned long long* queue;
-    int* counter;  // LDS: general triangles, [0, capacity)
-    int capacity;  // of each third
-    int* counter_mid;  // LDS: midpoint triangles, [capacity, 2 capacity)
-    int* counter_cen;  // LDS: centroid triangles, [2 capacity, 3 capacity)
-    bool drop;         // development (dbg_flags & 1024): timing only, nothing is queued
-    // A queue that is full (white noise at 50 % occupancy: 97 k midpoint triangles against 83 k entries; no texture map comes
-    // near) drops the triangle and raises this flag: the caller hands the SITE to the general walk, which walks its star again
-    // and rasterises in place -- rasterising a triangle twice is harmless.  (Until round 3 the triangle was rasterised right
-    // here: three inlined copies of RasterEmit in the lean loop, 2500 vector instructions of loop body for a path no render takes.)
-    mutable bool full;
+    int* counter;  // LDS
+    int capacity;  // H W
+    bool drop;     // development (dbg_flags & 1024): timing only, nothing is queued
+    int32_t* status;
     __device__ __forceinline__ void operator()(int ax, int ay, int bx, int by, int cx, int cy) const {
         if (drop) return;
-        // most triangles of a densely covered region are unit lattice triangles (twice the area = 1): no lattice point
-        // other than the vertices lies in them (Pick), nothing to interpolate
         const int32_t area = sd_orient(ax, ay, bx, by, cx, cy);
         if (area <= 1) return;
-        if (area == 2) {
-            int px = cx, py = cy, qx = ax, qy = ay;                                  // edge c-a unless ...
-            if ((((bx - ax) | (by - ay)) & 1) == 0) { px = ax; py = ay; qx = bx; qy = by; }
-            else if ((((cx - bx) | (cy - by)) & 1) == 0) { px = bx; py = by; qx = cx; qy = cy; }
-            const int slot = atomicAdd(counter_mid, 1);
-            if (slot < capacity) {
-                const int mx = (px + qx) >> 1, my = (py + qy) >> 1;
-                const uint32_t half = (uint32_t)((qx - mx) & 0xFF) | ((uint32_t)((qy - my) & 0xFF) << 8);
-                store_wb(queue + capacity + slot, ((unsigned long long)half << 32) | ((uint32_t)my << 16) | (uint32_t)mx);
-            } else {
-                full = true;
-            }
-            return;
-        }
-        if (area == 3 && (ax + bx + cx) % 3 == 0 && (ay + by + cy) % 3 == 0) {
-            // twice-the-area 3 with a lattice centroid: that is the triangle's one interior point (and its boundary holds
-            // no lattice point), weights 1 : 1 : 1 over 3.  (The other kind of area 3 has two points on one edge: general.)
-            const int slot = atomicAdd(counter_cen, 1);
-            if (slot < capacity) {
-                const int mx = (ax + bx + cx) / 3, my = (ay + by + cy) / 3;
-                const uint32_t rel = (uint32_t)((ax - mx) & 0xFF) | ((uint32_t)((ay - my) & 0xFF) << 8) |
-                                     ((uint32_t)((bx - mx) & 0xFF) << 16) | ((uint32_t)((by - my) & 0xFF) << 24);
-                store_wb(queue + 2 * capacity + slot, ((unsigned long long)rel << 32) | ((uint32_t)my << 16) | (uint32_t)mx);
-            } else {
-                full = true;
-            }
-            return;
-        }
         const int slot = atomicAdd(counter, 1);
         if (slot < capacity) {
             const uint32_t rel = (uint32_t)((bx - ax) & 0xFF) | ((uint32_t)((by - ay) & 0xFF) << 8) |
                                  ((uint32_t)((cx - ax) & 0xFF) << 16) | ((uint32_t)((cy - ay) & 0xFF) << 24);
             store_wb(queue + slot, ((unsigned long long)rel << 32) | ((uint32_t)ay << 16) | (uint32_t)ax);
-        } else {
-            full = true;
+        } else if (status) {
+            atomicOr(status, SALVE_STATUS_WALK_FAILED);   // (unreachable by the bound above; never silently)
         }
     }
 };
@@ -711,7 +676,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     if (!degenerate && !(c.dbg_flags & 1)) {
         SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13], (H <= 1024 && W <= 1024 && !(c.dbg_flags & 256)) ? tri_cache : nullptr};
         RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (c.dbg_flags & 2) != 0};
-        QueueEmit qemit = {triq, &scal[8], (H * W) / 3, &scal[15], &scal[16], (c.dbg_flags & 1024) != 0, false};
+        QueueEmit qemit = {triq, &scal[8], H * W, (c.dbg_flags & 1024) != 0, status};
         const int hard_cap = (H * W) >> 1;   // entries of two words: the site, and where its lean walk stood
         SdLean st;
         bool active = false, exhausted = false;
@@ -737,14 +702,8 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                 break;  // every lane is exhausted and idle
             }
             if (active) {
-                int r = sdl_lean_step(st, g, qemit);
+                const int r = sdl_lean_step(st, g, qemit);
                 iters++;
-                if (qemit.full) {   // a triangle of this site found its queue full: the general walk takes the whole site
-                    qemit.full = false;
-                    active = false;
-                    push_hard(hardlist, &scal[7], hard_cap, ((uint32_t)st.sy << 16) | (uint32_t)st.sx, HARD_FRESH, status);
-                    r = SDL_LEAN_CONTINUE;
-                }
                 if (r != SDL_LEAN_CONTINUE) {
                     active = false;
                     if (dbg_mask && (c.dbg_flags & 16))  // development: how each site's lean walk ended
@@ -767,8 +726,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
         SD_PHASE(1, t_phase);
 #endif
         const int nhard = min(scal[7], hard_cap);
-        const int qcap = (H * W) / 3;
-        const int nq = min(scal[8], qcap), nmid = min(scal[15], qcap), ncen = min(scal[16], qcap);
+        const int nq = min(scal[8], H * W);
         int err = 0;
 #if defined(SALVE_PROFILE_WALK)
         long long t_e2 = SD_NOW();
@@ -813,40 +771,59 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             // a star walk that did not close: the image of this render is incomplete -- tell the host (salve_hip.h: status word)
             if (status && (lane & (E2_GROUP - 1)) == 0) atomicOr(status, SALVE_STATUS_WALK_FAILED);
         }
+        // ---- phase F: the queued triangles.  Two in three have twice-the-area 2: by Pick exactly one lattice point besides the
+        //      vertices, the MIDPOINT of their one edge with an even difference vector, colour floor((p + q) / 2); another
+        //      fifth has twice-the-area 3 and a lattice centroid, its one interior point, colour floor((a + b + c) / 3).  Those
+        //      are filled right here (a dozen instructions each); the general triangles -- a loop over rows and pixels -- are
+        //      only listed (their queue index, in the dead site list) and rasterised in a second pass, so that no wavefront
+        //      runs at the pace of its general ones.
+        uint32_t* genlist = sitelist;
         for (int i = tid; i < ((c.dbg_flags & 8) ? 0 : nq); i += DENSIFY_THREADS) {
             const unsigned long long e = __hip_atomic_load(triq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int ax = (int)(e & 0xFFFFu), ay = (int)((e >> 16) & 0xFFFFu);
             const uint32_t rel = (uint32_t)(e >> 32);
+            const int bx = ax + (int8_t)(rel & 0xFF), by = ay + (int8_t)((rel >> 8) & 0xFF), cx = ax + (int8_t)((rel >> 16) & 0xFF), cy = ay + (int8_t)(rel >> 24);
+            const int32_t area = sd_orient(ax, ay, bx, by, cx, cy);
+            const bool centroid = area == 3 && (ax + bx + cx) % 3 == 0 && (ay + by + cy) % 3 == 0;   // (the other kind of area 3 has two points on one edge: general)
+            if (area != 2 && !centroid) {
+                store_wb(genlist + atomicAdd(&scal[15], 1), (uint32_t)i);
+                continue;
+            }
+            if (c.dbg_flags & 2) continue;
+            if (area == 2) {
+                int px = cx, py = cy, qx = ax, qy = ay;                                  // edge c-a unless ...
+                if ((((bx - ax) | (by - ay)) & 1) == 0) { px = ax; py = ay; qx = bx; qy = by; }
+                else if ((((cx - bx) | (cy - by)) & 1) == 0) { px = bx; py = by; qx = cx; qy = cy; }
+                const int mx = (px + qx) >> 1, my = (py + qy) >> 1;
+                if (!(((msk[my * wpr + (mx >> 5)] & ~occ[my * wpr + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
+                const uint32_t cp = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - py : py) * W + px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cq = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - qy : qy) * W + qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // floor((p + q) / 2) in each of the three colour bytes at once
+                bev[(size_t)(flip >= 0 ? flip - my : my) * W + mx] = (((cp & 0xFEFEFEu) >> 1) + ((cq & 0xFEFEFEu) >> 1) + (cp & cq & 0x010101u));
+            } else {
+                const int mx = (ax + bx + cx) / 3, my = (ay + by + cy) / 3;
+                if (!(((msk[my * wpr + (mx >> 5)] & ~occ[my * wpr + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
+                const uint32_t ca = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - ay : ay) * W + ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cb = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - by : by) * W + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cc = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - cy : cy) * W + cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t out = 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const uint32_t sum = ((ca >> (8 * ch)) & 255u) + ((cb >> (8 * ch)) & 255u) + ((cc >> (8 * ch)) & 255u);
+                    out |= ((sum * 0xAAABu) >> 17) << (8 * ch);   // floor(sum / 3), exact below 2^16
+                }
+                bev[(size_t)(flip >= 0 ? flip - my : my) * W + mx] = out;
+            }
+        }
+        wg_barrier_after_global_stores();   // the list of general triangles is complete and in L2
+        const int ngen = min(scal[15], H * W);
+        for (int i = tid; i < ngen; i += DENSIFY_THREADS) {
+            const uint32_t qi = __hip_atomic_load(genlist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long e = __hip_atomic_load(triq + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ax = (int)(e & 0xFFFFu), ay = (int)((e >> 16) & 0xFFFFu);
+            const uint32_t rel = (uint32_t)(e >> 32);
             raster(ax, ay, ax + (int8_t)(rel & 0xFF), ay + (int8_t)((rel >> 8) & 0xFF), ax + (int8_t)((rel >> 16) & 0xFF),
                    ay + (int8_t)(rel >> 24));
-        }
-        for (int i = tid; i < ((c.dbg_flags & (8 | 2)) ? 0 : nmid); i += DENSIFY_THREADS) {   // midpoint triangles
-            const unsigned long long e = __hip_atomic_load(triq + qcap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int mx = (int)(e & 0xFFFFu), my = (int)((e >> 16) & 0xFFFFu);
-            const int dx = (int8_t)((e >> 32) & 0xFF), dy = (int8_t)((e >> 40) & 0xFF);
-            if (!(((msk[my * wpr + (mx >> 5)] & ~occ[my * wpr + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
-            const uint32_t cp = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - (my - dy) : my - dy) * W + (mx - dx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t cq = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - (my + dy) : my + dy) * W + (mx + dx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // floor((p + q) / 2) in each of the three colour bytes at once
-            bev[(size_t)(flip >= 0 ? flip - my : my) * W + mx] = (((cp & 0xFEFEFEu) >> 1) + ((cq & 0xFEFEFEu) >> 1) + (cp & cq & 0x010101u));
-        }
-        for (int i = tid; i < ((c.dbg_flags & (8 | 2)) ? 0 : ncen); i += DENSIFY_THREADS) {   // centroid triangles
-            const unsigned long long e = __hip_atomic_load(triq + 2 * qcap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int mx = (int)(e & 0xFFFFu), my = (int)((e >> 16) & 0xFFFFu);
-            if (!(((msk[my * wpr + (mx >> 5)] & ~occ[my * wpr + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
-            const int ax = mx + (int8_t)((e >> 32) & 0xFF), ay = my + (int8_t)((e >> 40) & 0xFF);
-            const int bx = mx + (int8_t)((e >> 48) & 0xFF), by = my + (int8_t)((e >> 56) & 0xFF);
-            const int cx = 3 * mx - ax - bx, cy = 3 * my - ay - by;
-            const uint32_t ca = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - ay : ay) * W + ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t cb = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - by : by) * W + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t cc = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - cy : cy) * W + cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t out = 0;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const uint32_t sum = ((ca >> (8 * ch)) & 255u) + ((cb >> (8 * ch)) & 255u) + ((cc >> (8 * ch)) & 255u);
-                out |= ((sum * 0xAAABu) >> 17) << (8 * ch);   // floor(sum / 3), exact below 2^16
-            }
-            bev[(size_t)(flip >= 0 ? flip - my : my) * W + mx] = out;
         }
     }
     // ---- phase G: data pixels outside the mask are 0 in the result (all of them if the interpolation early-outs).
