@@ -285,15 +285,32 @@ struct RasterEmit {
     int lane, nlanes;  // rows lane, lane + nlanes, ... of the bounding box (several lanes may share one triangle)
     bool skip;
 
-    __device__ __forceinline__ uint32_t blend(int32_t wa, int32_t wb, int32_t wc, int32_t area, uint32_t ca,
-                                              uint32_t cb, uint32_t cc) const {
+    // floor(n / d) for d > 0, |n| < 2^23, with inv_d ~ 1 / d: the float quotient is within 1 of the answer (n is exact in float32,
+    // the product is off by 2^-22 relative at most), and the remainder says which way.  The GPU
+    // has no integer divide: the compiler's expansion is ~35 instructions, and the span of a wide triangle needs three per row.
+    static __device__ __forceinline__ int floor_div(int n, int d, float inv_d) {
+        int q = (int)floorf((float)n * inv_d);
+        const int r = n - q * d;
+        q += (r >= d) ? 1 : 0;
+        q -= (r < 0) ? 1 : 0;
+        return q;
+    }
+
+    // floor((wa ca + wb cb + wc cc) / area) per colour byte, exactly: weights < area < 2^23 (coordinates < 2048), colours < 256, so
+    // the numerator is below 2^31 and 24-bit multiply-adds compute it exactly; the quotient (<= 255) comes from a float product
+    // that is within 6e-5 of it, fixed up with the exact remainder.  (Until round 3: int64 products and a float64 division --
+    // ~150 cycles per pixel where this takes ~40.)
+    static __device__ __forceinline__ uint32_t blend(int32_t wa, int32_t wb, int32_t wc, int32_t area, float inv_area, uint32_t ca,
+                                                     uint32_t cb, uint32_t cc) {
         uint32_t out = 0;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const int64_t num = (int64_t)wa * ((ca >> (8 * ch)) & 255) + (int64_t)wb * ((cb >> (8 * ch)) & 255) +
-                                (int64_t)wc * ((cc >> (8 * ch)) & 255);
-            // floor of the exact rational; the double quotient cannot round across an integer (num < 2^53, area < 2^23)
-            const uint32_t q = (uint32_t)((double)num / (double)area);
+            const uint32_t num = __umul24((uint32_t)wa, (ca >> (8 * ch)) & 255u) + __umul24((uint32_t)wb, (cb >> (8 * ch)) & 255u) +
+                                 __umul24((uint32_t)wc, (cc >> (8 * ch)) & 255u);
+            uint32_t q = (uint32_t)((float)num * inv_area);
+            const int32_t r = (int32_t)(num - __umul24(q, (uint32_t)area));
+            q += (r >= area) ? 1u : 0u;
+            q -= (r < 0) ? 1u : 0u;
             out |= q << (8 * ch);
         }
         return out;
@@ -308,27 +325,33 @@ struct RasterEmit {
         uint32_t ca = 0, cb = 0, cc = 0;
         bool have = false;
         const bool wide = (x1 - x0) > 40;
+        const float inv_area = 1.0f / (float)area;
+        // the three edge functions E_i(x, y) = A_i x + Bx_i (y - Py_i) + C_i >= 0 inside (counter-clockwise), for the exact
+        // span of a wide triangle on a row
+        const int ex[3][4] = {{bx, by, cx, cy}, {cx, cy, ax, ay}, {ax, ay, bx, by}};
+        int eA[3], eB[3], eC[3];
+        float einv[3];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const int px = ex[e][0], py = ex[e][1], qx = ex[e][2], qy = ex[e][3];
+            eA[e] = -(qy - py);
+            eB[e] = qx - px;
+            eC[e] = (qy - py) * px - (qx - px) * py;   // E(x, y) = eA x + eB y + eC
+            einv[e] = eA[e] != 0 ? 1.0f / (float)(eA[e] < 0 ? -eA[e] : eA[e]) : 0.f;
+        }
         for (int y = y0 + lane; y <= y1; y += nlanes) {
             int xa = x0, xb = x1;
             if (wide) {
-                // exact span of the triangle on this row: intersect the three half-planes E_i(x) = A_i x + D_i >= 0
-                const int ex[3][4] = {{bx, by, cx, cy}, {cx, cy, ax, ay}, {ax, ay, bx, by}};
+                // exact span of the triangle on this row: intersect the three half-planes A_i x + D_i >= 0
                 bool empty = false;
 #pragma unroll
                 for (int e = 0; e < 3; e++) {
-                    const int px = ex[e][0], py = ex[e][1], qx = ex[e][2], qy = ex[e][3];
-                    const int32_t A = -(qy - py);
-                    const int32_t D = (qx - px) * (y - py) + (qy - py) * px;
+                    const int32_t A = eA[e];
+                    const int32_t D = eB[e] * y + eC[e];
                     if (A > 0) {  // x >= ceil(-D / A)
-                        int32_t n = -D;
-                        int32_t q = n / A;
-                        if (n % A > 0) q++;
-                        xa = max(xa, q);
+                        xa = max(xa, floor_div(-D + A - 1, A, einv[e]));
                     } else if (A < 0) {  // x <= floor(D / -A)
-                        int32_t m = -A;
-                        int32_t q = D / m;
-                        if (D % m < 0) q--;
-                        xb = min(xb, q);
+                        xb = min(xb, floor_div(D, -A, einv[e]));
                     } else if (D < 0) {
                         empty = true;
                     }
@@ -355,7 +378,7 @@ struct RasterEmit {
                         cc = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - cy : cy) * W + cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         have = true;
                     }
-                    bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = blend(wa, wb, wc, area, ca, cb, cc);
+                    bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = blend(wa, wb, wc, area, inv_area, ca, cb, cc);
                 }
             }
         }
