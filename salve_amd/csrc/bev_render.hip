@@ -775,9 +775,15 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                 if (gw.lane == 0) i0 = atomicAdd(&scal[11], HARD_RUN);
                 i0 = __shfl(i0, gw.gbase);
                 if (i0 >= nh) break;
+                // the run's entries in ONE load (lane l holds word l of the run), handed out by lane reads: one trip to L2 per
+                // run instead of two dependent ones per site
+                static_assert(2 * HARD_RUN <= E2_GROUP, "a run's entries are fetched by one load of the group");
+                uint32_t run_words = 0;
+                if (gw.lane < 2 * HARD_RUN && 2 * i0 + gw.lane < 2 * nh)
+                    run_words = __hip_atomic_load(hardlist + 2 * i0 + gw.lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (int i = i0; i < min(i0 + HARD_RUN, nh); i++) {
-                    const uint32_t s = __hip_atomic_load(hardlist + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t w = __hip_atomic_load(hardlist + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t s = (uint32_t)__shfl((int)run_words, gw.gbase + 2 * (i - i0));
+                    const uint32_t w = (uint32_t)__shfl((int)run_words, gw.gbase + 2 * (i - i0) + 1);
                     const int hx = (int)(s & 0xFFFFu), hy = (int)(s >> 16);
                     const int r = sd_walk(gw, hx, hy, (w & HARD_FRESH) != 0, (int)(w & 0xFF) - 128, (int)((w >> 8) & 0xFF) - 128, (w >> 20) & 1u ? 1 : -1,
                                           ((w >> 21) & 1u) != 0, (int)((w >> 16) & 3u) - 1, (int)((w >> 18) & 3u) - 1, rw);
