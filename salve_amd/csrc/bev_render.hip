@@ -183,8 +183,10 @@ __global__ __launch_bounds__(SCATTER_THREADS) void bev_scatter_kernel(
                 }
                 if (c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax) {
                     // bevimg_Sim2_world.transform_from: (p @ I.T + t) * s, then np.round (half to even)
-                    const double fx = rint((fma(y1, 0.0, x1 * 1.0) + c.tx) * c.scale);
-                    const double fy = rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
+                    // (the reference multiplies by the identity first, fma(y1, 0, x1 * 1) = x1 and fma(y1, 1, x1 * 0) = y1 for the finite
+                    // values that pass the window test -- up to the sign of a zero, which the rounding to an integer index erases)
+                    const double fx = rint((x1 + c.tx) * c.scale);
+                    const double fy = rint((y1 + c.ty) * c.scale);
                     ix = (int)fx;
                     iy = (int)fy;
                     my_in_window++;
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(256) void bev_scatter_points_kernel(DevCfg c, const
     const double x1 = xyz[3 * (size_t)i], y1 = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
     if (!(c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax)) return;
     atomicAdd(n_in_window, 1);
-    const int ix = (int)rint((fma(y1, 0.0, x1 * 1.0) + c.tx) * c.scale);
-    const int iy = (int)rint((fma(y1, 1.0, x1 * 0.0) + c.ty) * c.scale);
+    const int ix = (int)rint((x1 + c.tx) * c.scale);   // (identity product dropped, as in bev_scatter_kernel)
+    const int iy = (int)rint((y1 + c.ty) * c.scale);
     const double zs = floor(z) - c.zmin;
     if (!(zs >= 0.0 && zs < (double)c.nslices) || ix < 0 || ix >= c.W || iy < 0 || iy >= c.H) return;
     atomicMax(kimg + (size_t)iy * c.W + ix, ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | (uint32_t)i);
