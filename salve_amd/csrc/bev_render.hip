@@ -711,7 +711,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             // instead of in nearly every iteration, at the price of a few lane-iterations of idling.
             const unsigned long long idle = __ballot(!active && !exhausted);
             const unsigned long long busy = __ballot(active);
-            if (idle != 0ull && (__popcll(idle) >= 16 || busy == 0ull)) {
+            if (idle != 0ull && (__popcll(idle) >= 16 || busy == 0ull)) {   // (thresholds of 24 ... 48 measured the same or worse, round 3)
                 if (!active && !exhausted) {
                     const int i = atomicAdd(&scal[6], 1);
                     if (i >= nsites) {

@@ -21,11 +21,20 @@
 
 // 32 bits of bitmap row y starting at column x0 (may be negative / beyond the image: zeros)
 SD_FN uint32_t sdl_row32(const SdGrid& g, int y, int x0) {
-    if (y < 0 || y >= g.H) return 0u;
+    // branch-free, like sdl_bit: words beyond the image are read at index 0 and masked (each guarded load was an exec-mask
+    // round trip, six of them per site in sdl_lean_begin)
+    const bool yin = (unsigned)y < (unsigned)g.H;
     const int w0 = x0 >> 5, sh = x0 & 31;  // arithmetic shift: floor
-    const uint32_t lo = (w0 >= 0 && w0 < g.wpr) ? g.occ[y * g.wpr + w0] : 0u;
-    const uint32_t hi = (w0 + 1 >= 0 && w0 + 1 < g.wpr) ? g.occ[y * g.wpr + w0 + 1] : 0u;
+    const bool in0 = yin & ((unsigned)w0 < (unsigned)g.wpr), in1 = yin & ((unsigned)(w0 + 1) < (unsigned)g.wpr);
+    const int base = (yin ? y : 0) * g.wpr;
+    uint32_t lo = g.occ[base + (in0 ? w0 : 0)], hi = g.occ[base + (in1 ? w0 + 1 : 0)];
+    lo = in0 ? lo : 0u;
+    hi = in1 ? hi : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);   // (hi : lo) >> sh, sh = 0 .. 31
+#else
     return sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+#endif
 }
 
 SD_FN bool sdl_bit(const SdGrid& g, int x, int y) {
