@@ -242,6 +242,11 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
     float4 bias_v[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) bias_v[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wc * 64 + j * 16 + 4 * frag_q);
+    // (one 64-bit row offset per thread, then a scalar step per iteration: a v_mad_i64_i32 per copy otherwise)
+    constexpr int ROW_STEP = C8_THREADS / CH_PER_ROW;
+    const int crow = tid / CH_PER_ROW, cch = tid % CH_PER_ROW;
+    const long long coff = (long long)(m0 + crow) * p.Cout + n0 + cch * 8;
+    const int cstep = ROW_STEP * p.Cout;
     if (p.res) {
         constexpr int RB = 8;
 #pragma unroll
@@ -249,16 +254,12 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
             uint4 rv[RB];
 #pragma unroll
             for (int u = 0; u < RB; u++) {
-                const int id = tid + (it0 + u) * C8_THREADS;
-                const int m = m0 + id / CH_PER_ROW;
-                const long long off = (long long)(m < p.M ? m : 0) * p.Cout + n0 + (id % CH_PER_ROW) * 8;
-                rv[u] = *reinterpret_cast<const uint4*>(p.res + off);
+                const bool in = m0 + crow + (it0 + u) * ROW_STEP < p.M;   // (rows beyond M read row m0: any valid address, the value is not stored)
+                rv[u] = *reinterpret_cast<const uint4*>(p.res + (in ? coff + (long long)(it0 + u) * cstep : (long long)m0 * p.Cout + n0));
             }
 #pragma unroll
-            for (int u = 0; u < RB; u++) {
-                const int id = tid + (it0 + u) * C8_THREADS;
-                *reinterpret_cast<uint4*>(Cs + (id / CH_PER_ROW) * LDC + (id % CH_PER_ROW) * 8) = rv[u];
-            }
+            for (int u = 0; u < RB; u++)
+                *reinterpret_cast<uint4*>(Cs + (crow + (it0 + u) * ROW_STEP) * LDC + cch * 8) = rv[u];
         }
         __syncthreads();
     }
@@ -283,11 +284,8 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
     __syncthreads();
 #pragma unroll 4
     for (int it = 0; it < C_ITERS; it++) {
-        const int id = tid + it * C8_THREADS;
-        const int r = id / CH_PER_ROW, ch = id % CH_PER_ROW;
-        const int m = m0 + r;
-        if (m < p.M)
-            *reinterpret_cast<uint4*>(p.out + (long long)m * p.Cout + n0 + ch * 8) = *reinterpret_cast<const uint4*>(Cs + r * LDC + ch * 8);
+        if (m0 + crow + it * ROW_STEP < p.M)
+            *reinterpret_cast<uint4*>(p.out + coff + (long long)it * cstep) = *reinterpret_cast<const uint4*>(Cs + (crow + it * ROW_STEP) * LDC + cch * 8);
     }
 }
 

@@ -305,15 +305,17 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     uint16_t* Cs = smem;
     constexpr int CH_PER_ROW = BN / 8;
     constexpr int C_ITERS = (BM * CH_PER_ROW) / CONV_THREADS;
+    // (one 64-bit row offset per thread, then a scalar step per iteration: a v_mad_i64_i32 per copy otherwise)
+    constexpr int ROW_STEP = CONV_THREADS / CH_PER_ROW;
+    const int crow = tid / CH_PER_ROW, cch = tid % CH_PER_ROW;
+    const long long coff = (long long)(m0 + crow) * p.Cout + n0 + cch * 8;
+    const int cstep = ROW_STEP * p.Cout;
     if (p.res) {
 #pragma unroll
         for (int it = 0; it < C_ITERS; it++) {
-            const int id = tid + it * CONV_THREADS;
-            const int r = id / CH_PER_ROW, ch = id % CH_PER_ROW;
-            const int m = m0 + r;
             uint4 v = uint4{0u, 0u, 0u, 0u};
-            if (m < p.M) v = *reinterpret_cast<const uint4*>(p.res + (long long)m * p.Cout + n0 + ch * 8);
-            *reinterpret_cast<uint4*>(Cs + r * LDC + ch * 8) = v;
+            if (m0 + crow + it * ROW_STEP < p.M) v = *reinterpret_cast<const uint4*>(p.res + coff + it * cstep);
+            *reinterpret_cast<uint4*>(Cs + (crow + it * ROW_STEP) * LDC + cch * 8) = v;
         }
         __syncthreads();
     }
@@ -339,11 +341,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < C_ITERS; it++) {
-        const int id = tid + it * CONV_THREADS;
-        const int r = id / CH_PER_ROW, ch = id % CH_PER_ROW;
-        const int m = m0 + r;
-        if (m < p.M)
-            *reinterpret_cast<uint4*>(p.out + (long long)m * p.Cout + n0 + ch * 8) = *reinterpret_cast<const uint4*>(Cs + r * LDC + ch * 8);
+        if (m0 + crow + it * ROW_STEP < p.M)
+            *reinterpret_cast<uint4*>(p.out + coff + it * cstep) = *reinterpret_cast<const uint4*>(Cs + (crow + it * ROW_STEP) * LDC + cch * 8);
     }
 }
 
