@@ -10,8 +10,15 @@ short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").
 line = lambda f: json.loads([x for x in open(SRC / f) if x.startswith("{")][-1])
 VER = ("conv_igemm", "conv8_kernel", "bottleneck", "stem_pool", "maxpool", "avgpool", "expand_chain")
 
+import os
+def newest(pattern, recursive=False):
+    # gpurun merges a call's files INTO gpurun_out/ without deleting those of earlier calls, and rocprofv3 names its files after
+    # the process id: take the newest match, never all of them
+    files = glob.glob(pattern, recursive=recursive)
+    return max(files, key=os.path.getmtime)
+
 def stats(d, title, tag, n_rows=16):
-    f = glob.glob(str(SRC / d / "*" / "*kernel_stats.csv"))[0]
+    f = newest(str(SRC / d / "*" / "*kernel_stats.csv"))
     shutil.copy(f, PRO / f"r03_bench_kernel_stats{tag}.csv")
     rows = list(csv.DictReader(open(f)))
     out = title + ["", "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
@@ -66,7 +73,7 @@ for name in kn:
 # ---- rasteriser traffic at the benchmark's launch shape (4096 renders per launch, 64 panoramas)
 def pmc(sub, counter):
     acc = collections.defaultdict(list)
-    for f in glob.glob(str(SRC / sub / "**" / "*counter_collection.csv"), recursive=True):
+    for f in [newest(str(SRC / sub / "**" / "*counter_collection.csv"), recursive=True)]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter and "bev_" in r["Kernel_Name"]:
                 acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
