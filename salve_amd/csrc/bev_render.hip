@@ -286,6 +286,9 @@ struct RasterEmit {
     int flip;       // H - 1 to flip vertically (np.flipud), -1: no flip
     int lane, nlanes;  // rows lane, lane + nlanes, ... of the bounding box (several lanes may share one triangle)
     bool skip;
+    // pixel (x, y) of the output image as a 32-bit element index (the image is smaller than 2048 x 2048; a 64-bit index product is
+    // a quarter-rate v_mad_u64_u32 per access)
+    __device__ __forceinline__ uint32_t pix(int x, int y) const { return (uint32_t)(((flip >= 0 ? flip - y : y) * W) + x); }
 
     // floor(n / d) for d > 0, |n| < 2^23, with inv_d ~ 1 / d: the float quotient is within 1 of the answer (n is exact in float32,
     // the product is off by 2^-22 relative at most), and the remainder says which way.  The GPU
@@ -361,7 +364,7 @@ struct RasterEmit {
                 if (empty || xa > xb) continue;
             }
             for (int w = xa >> 5; w <= (xb >> 5); w++) {
-                uint32_t bits = msk[y * wpr + w] & ~occ[y * wpr + w];
+                uint32_t bits = msk[(y * wpr) + w] & ~occ[(y * wpr) + w];
                 const int lo = xa - (w << 5), hi = xb - (w << 5);
                 if (lo > 0) bits &= 0xFFFFFFFFu << lo;
                 if (hi < 31) bits &= 0xFFFFFFFFu >> (31 - hi);
@@ -375,12 +378,12 @@ struct RasterEmit {
                     if (!have) {
                         // vertex colours from the output image, where phase B of this workgroup put them: read past
                         // the L1 (the stores went to L2; the L1 may hold older lines of these addresses)
-                        ca = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - ay : ay) * W + ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        cb = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - by : by) * W + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        cc = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - cy : cy) * W + cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ca = __hip_atomic_load(bev + pix(ax, ay), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        cb = __hip_atomic_load(bev + pix(bx, by), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        cc = __hip_atomic_load(bev + pix(cx, cy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         have = true;
                     }
-                    bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = blend(wa, wb, wc, area, inv_area, ca, cb, cc);
+                    bev[pix(x, y)] = blend(wa, wb, wc, area, inv_area, ca, cb, cc);
                 }
             }
         }
@@ -473,10 +476,19 @@ static int ensure_star_table() {
     return SALVE_OK;
 }
 
+// DEV = false is the product kernel: the development outputs (mask image, work counters) and the development flags of the
+// configuration (phases switched off for timing, tools/densify_*.py) are compiled OUT -- their pointers and tests kept a dozen
+// scalar registers live through every loop of a kernel that runs at the limit of the scalar register file (100 spills), and
+// where the spill reloads land decides 10 % of its vector instructions (round 3).  DEV = true is launched whenever a caller
+// passes a debug buffer or a non-zero flag word.
+template <bool DEV>
 __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     DensifyCfg c, uint32_t* __restrict__ keys_all, const int32_t* __restrict__ bbox_all, const uint8_t* const* __restrict__ colour_src, uint32_t* __restrict__ bev_all,
     uint32_t* __restrict__ sitelist_all, uint32_t* __restrict__ hardlist_all, unsigned long long* __restrict__ triq_all,
-    uint8_t* __restrict__ dbg_mask, int32_t* __restrict__ dbg_stats, int16_t* __restrict__ dbg_aux, int32_t* __restrict__ status) {
+    uint8_t* __restrict__ dbg_mask_arg, int32_t* __restrict__ dbg_stats_arg, int16_t* __restrict__ dbg_aux, int32_t* __restrict__ status) {
+    uint8_t* const dbg_mask = DEV ? dbg_mask_arg : nullptr;
+    int32_t* const dbg_stats = DEV ? dbg_stats_arg : nullptr;
+    const int dbg_flags = DEV ? c.dbg_flags : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = c.H, W = c.W, wpr = c.wpr;
     uint32_t* occ = reinterpret_cast<uint32_t*>(smem);
@@ -493,6 +505,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     const uint8_t* colours = colour_src[rid];
     const int flip = (c.out_flags & 1) ? -1 : H - 1;
     uint32_t* bev = bev_all + (size_t)rid * H * W;
+    auto pixi = [&](int x, int y) -> uint32_t { return (uint32_t)((flip >= 0 ? flip - y : y) * W + x); };   // pixel (x, y) of the output image, 32-bit element index (RasterEmit::pix)
     uint32_t* sitelist = sitelist_all + (size_t)rid * H * W;
     uint32_t* hardlist = hardlist_all + (size_t)rid * H * W;
     unsigned long long* triq = triq_all + (size_t)rid * H * W;
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
         const bool whole_row = nseg <= ROW_SEGS;
         const bool row_in = y >= y_lo && y <= y_hi;
         if (!row_in) {   // (wave-uniform) nothing to read: empty bitmap rows, zero output row
-            for (int x = lane; x < W; x += 64) bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = 0u;
+            for (int x = lane; x < W; x += 64) bev[pixi(x, y)] = 0u;
             for (int w = lane; w < wpr; w += 64) { occ[y * wpr + w] = 0u; msk[y * wpr + w] = 0u; }
             if (lane == 0) { rmin[y] = (int16_t)W; rmax[y] = (int16_t)-1; }
             continue;
@@ -575,7 +588,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                 const bool site = key != 0;
                 // the output image starts as the sparse image: data pixels carry their colour (they are also the vertex
                 // colours the rasteriser reads back), everything else is 0
-                if (x < W) bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = col;
+                if (x < W) bev[pixi(x, y)] = col;
                 const uint32_t r = col & 255u, gch = (col >> 8) & 255u, b = (col >> 16) & 255u;
                 const bool ne = site && (((r * gch * b) & 255u) != 0);
                 ob = __ballot(site);
@@ -698,10 +711,10 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     //          never idle; owned triangles are queued; sites whose star does not fit the window go to the hard list.
     //      E2: hard sites (hull, sparse regions: a few %) walk their star with the general algorithm and rasterise
     //          in place.   F: all lanes rasterise the queued triangles.
-    if (!degenerate && !(c.dbg_flags & 1)) {
-        SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (c.dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13], (H <= 1024 && W <= 1024 && !(c.dbg_flags & 256)) ? tri_cache : nullptr};
-        RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (c.dbg_flags & 2) != 0};
-        QueueEmit qemit = {triq, &scal[8], H * W, (c.dbg_flags & 1024) != 0, status};
+    if (!degenerate && !(dbg_flags & 1)) {
+        SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13], (H <= 1024 && W <= 1024 && !(dbg_flags & 256)) ? tri_cache : nullptr};
+        RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (dbg_flags & 2) != 0};
+        QueueEmit qemit = {triq, &scal[8], H * W, (dbg_flags & 1024) != 0, status};
         const int hard_cap = (H * W) >> 1;   // entries of two words: the site, and where its lean walk stood
         SdLean st;
         bool active = false, exhausted = false;
@@ -731,7 +744,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                 iters++;
                 if (r != SDL_LEAN_CONTINUE) {
                     active = false;
-                    if (dbg_mask && (c.dbg_flags & 16))  // development: how each site's lean walk ended
+                    if (dbg_mask && (dbg_flags & 16))  // development: how each site's lean walk ended
                     {
                         dbg_mask[((size_t)rid * H + st.sy) * W + st.sx] = (uint8_t)((r == SDL_LEAN_HARD ? 200 : 100) + min(st.deg, 50));
                     }
@@ -771,7 +784,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             // A group takes HARD_RUN consecutive list entries at a time: neighbours in the list are neighbours in the
             // image (the lean walk met them in raster order), and one group walking them one after the other finds the
             // triangles of the previous site in the cache instead of racing another group for them.
-            const int nh = (c.dbg_flags & 4) ? 0 : nhard;
+            const int nh = (dbg_flags & 4) ? 0 : nhard;
             for (;;) {
                 int i0 = 0;
                 if (gw.lane == 0) i0 = atomicAdd(&scal[11], HARD_RUN);
@@ -809,7 +822,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
         //      only listed (their queue index, in the dead site list) and rasterised in a second pass, so that no wavefront
         //      runs at the pace of its general ones.
         uint32_t* genlist = sitelist;
-        for (int i = tid; i < ((c.dbg_flags & 8) ? 0 : nq); i += DENSIFY_THREADS) {
+        for (int i = tid; i < ((dbg_flags & 8) ? 0 : nq); i += DENSIFY_THREADS) {
             const unsigned long long e = __hip_atomic_load(triq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int ax = (int)(e & 0xFFFFu), ay = (int)((e >> 16) & 0xFFFFu);
             const uint32_t rel = (uint32_t)(e >> 32);
@@ -820,30 +833,30 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                 store_wb(genlist + atomicAdd(&scal[15], 1), (uint32_t)i);
                 continue;
             }
-            if (c.dbg_flags & 2) continue;
+            if (dbg_flags & 2) continue;
             if (area == 2) {
                 int px = cx, py = cy, qx = ax, qy = ay;                                  // edge c-a unless ...
                 if ((((bx - ax) | (by - ay)) & 1) == 0) { px = ax; py = ay; qx = bx; qy = by; }
                 else if ((((cx - bx) | (cy - by)) & 1) == 0) { px = bx; py = by; qx = cx; qy = cy; }
                 const int mx = (px + qx) >> 1, my = (py + qy) >> 1;
-                if (!(((msk[my * wpr + (mx >> 5)] & ~occ[my * wpr + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
-                const uint32_t cp = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - py : py) * W + px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t cq = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - qy : qy) * W + qx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(((msk[(my * wpr) + (mx >> 5)] & ~occ[(my * wpr) + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
+                const uint32_t cp = __hip_atomic_load(bev + pixi(px, py), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cq = __hip_atomic_load(bev + pixi(qx, qy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // floor((p + q) / 2) in each of the three colour bytes at once
-                bev[(size_t)(flip >= 0 ? flip - my : my) * W + mx] = (((cp & 0xFEFEFEu) >> 1) + ((cq & 0xFEFEFEu) >> 1) + (cp & cq & 0x010101u));
+                bev[pixi(mx, my)] = (((cp & 0xFEFEFEu) >> 1) + ((cq & 0xFEFEFEu) >> 1) + (cp & cq & 0x010101u));
             } else {
                 const int mx = (ax + bx + cx) / 3, my = (ay + by + cy) / 3;
-                if (!(((msk[my * wpr + (mx >> 5)] & ~occ[my * wpr + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
-                const uint32_t ca = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - ay : ay) * W + ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t cb = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - by : by) * W + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t cc = __hip_atomic_load(bev + (size_t)(flip >= 0 ? flip - cy : cy) * W + cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(((msk[(my * wpr) + (mx >> 5)] & ~occ[(my * wpr) + (mx >> 5)]) >> (mx & 31)) & 1u)) continue;
+                const uint32_t ca = __hip_atomic_load(bev + pixi(ax, ay), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cb = __hip_atomic_load(bev + pixi(bx, by), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cc = __hip_atomic_load(bev + pixi(cx, cy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 uint32_t out = 0;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     const uint32_t sum = ((ca >> (8 * ch)) & 255u) + ((cb >> (8 * ch)) & 255u) + ((cc >> (8 * ch)) & 255u);
                     out |= ((sum * 0xAAABu) >> 17) << (8 * ch);   // floor(sum / 3), exact below 2^16
                 }
-                bev[(size_t)(flip >= 0 ? flip - my : my) * W + mx] = out;
+                bev[pixi(mx, my)] = out;
             }
         }
         wg_barrier_after_global_stores();   // the list of general triangles is complete and in L2
@@ -869,7 +882,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
         while (bits) {
             const int x = xb + __ffs((int)bits) - 1;
             bits &= bits - 1u;
-            bev[(size_t)(flip >= 0 ? flip - y : y) * W + x] = 0u;
+            bev[pixi(x, y)] = 0u;
         }
     }
     if (dbg_mask) {
@@ -883,7 +896,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
 #if defined(SALVE_PROFILE_WALK)
         SD_PHASE(4, t_phase);
         __syncthreads();
-        if (tid < 8) dbg_stats[rid * 8 + tid] = (c.dbg_flags & 128) ? sd_phase[tid] : (c.dbg_flags & 64) ? sd_timers[tid] : sd_counters[tid];
+        if (tid < 8) dbg_stats[rid * 8 + tid] = (dbg_flags & 128) ? sd_phase[tid] : (dbg_flags & 64) ? sd_timers[tid] : sd_counters[tid];
 #else
         if (tid < 8) dbg_stats[rid * 8 + tid] = tid == 1 ? scal[9] : (tid == 2 ? scal[10] : (tid < 6 ? scal[tid] : scal[tid + 1]));  // [1] sites begun [2] checksum [6] hard sites [7] queued triangles
 #endif
@@ -1260,7 +1273,9 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
             SALVE_HIP_CHECK(hipGetDevice(&dev));
             const int slot = (dev >= 0 && dev < 64) ? dev : 0;
             if (dev != slot || lds > attr_lds[slot]) {
-                SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel),
+                SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel<false>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SALVE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bev_densify_kernel<true>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_lds[slot] = lds;
             }
@@ -1272,8 +1287,12 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
             SALVE_HIP_CHECK(hipGetLastError());
         }
         const DensifyCfg dc = {d.H, d.W, d.wpr, d.mask_half, d.out_flags, d.dbg_flags};
-        hipLaunchKernelGGL(bev_densify_kernel, dim3(n), dim3(DENSIFY_THREADS), lds, s, dc, ws.keys, ws.bbox, ws.colour_src, out_bev, ws.sitelist,
-                           ws.hardlist, ws.triq, dbg_mask, dbg_stats, (d.dbg_flags & 16) ? dbg_img_xy : nullptr, status);
+        if (dbg_mask || dbg_stats || d.dbg_flags)   // development outputs or flags: the instantiation that has them
+            hipLaunchKernelGGL((bev_densify_kernel<true>), dim3(n), dim3(DENSIFY_THREADS), lds, s, dc, ws.keys, ws.bbox, ws.colour_src, out_bev, ws.sitelist,
+                               ws.hardlist, ws.triq, dbg_mask, dbg_stats, (d.dbg_flags & 16) ? dbg_img_xy : nullptr, status);
+        else
+            hipLaunchKernelGGL((bev_densify_kernel<false>), dim3(n), dim3(DENSIFY_THREADS), lds, s, dc, ws.keys, ws.bbox, ws.colour_src, out_bev, ws.sitelist,
+                               ws.hardlist, ws.triq, nullptr, nullptr, nullptr, status);
         SALVE_HIP_CHECK(hipGetLastError());
     }
     return SALVE_OK;

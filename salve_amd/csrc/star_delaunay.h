@@ -26,6 +26,20 @@
 
 #define SD_MAX_DIM 2048  // coordinates must be < 2048 for the int32 / int64 predicate bounds below
 
+// Products of coordinates, coordinate differences (|.| < 2^12) and bitmap row indices fit 24-bit operands: v_mul_i32_i24 runs at
+// the full vector rate, the 32-bit v_mul_lo_u32 the compiler must assume at a quarter of it -- and the predicates, the lambda of
+// a sweep candidate and every bitmap probe are made of these (round 3: 167 of them in the densify kernel).
+// (SD_MUL_DEVICE: __mul24 or a plain product -- the 24-bit form moved the kernel's SGPR spills INTO phase B's row loop in
+// three of four placements tried, which cost more than the multiplies saved)
+#ifndef SD_MUL_DEVICE
+#define SD_MUL_DEVICE(a, b) ((a) * (b))
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SD_MUL(a, b) SD_MUL_DEVICE((a), (b))
+#else
+#define SD_MUL(a, b) ((a) * (b))
+#endif
+
 struct SdGrid {
     int H, W, wpr;        // image height, width, 32-bit words per bitmap row
     const uint32_t* occ;  // [H][wpr] occupancy bits, bit (x & 31) of word x >> 5
@@ -104,11 +118,11 @@ SD_FN bool sd_occupied(const SdGrid& g, int x, int y) {
     // branch-free: an out-of-image probe reads word 0 and is masked (a guarded load costs an exec-mask round trip per probe)
     const bool in = (unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H;
     const int xi = in ? x : 0, yi = in ? y : 0;
-    return in & (bool)((g.occ[yi * g.wpr + (xi >> 5)] >> (xi & 31)) & 1u);
+    return in & (bool)((g.occ[SD_MUL(yi, g.wpr) + (xi >> 5)] >> (xi & 31)) & 1u);
 }
 
 SD_FN int32_t sd_orient(int ax, int ay, int bx, int by, int cx, int cy) {
-    return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
+    return SD_MUL(bx - ax, cy - ay) - SD_MUL(by - ay, cx - ax);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -181,7 +195,7 @@ SD_FN SdCircle sd_circle(int ax, int ay, int bx, int by, int cx, int cy) {
 
 // Bits of row y restricted to columns [x0, x1] of word w (x0 <= x1, both inside the image).
 SD_FN uint32_t sd_word_bits(const SdGrid& g, int y, int w, int x0, int x1) {
-    uint32_t bits = g.occ[y * g.wpr + w];
+    uint32_t bits = g.occ[SD_MUL(y, g.wpr) + w];
     int lo = x0 - (w << 5), hi = x1 - (w << 5);
     if (lo > 0) bits &= 0xFFFFFFFFu << lo;
     if (hi < 31) bits &= 0xFFFFFFFFu >> (31 - hi);
@@ -213,7 +227,7 @@ SD_FN bool sd_nearest(const SdGrid& g, int sx, int sy, int* nx, int* ny) {
                     int x = (w << 5) + sd_ctz(bits);
                     bits &= bits - 1;
                     if (x == sx && y == sy) continue;
-                    const int32_t d2 = (x - sx) * (x - sx) + (y - sy) * (y - sy);
+                    const int32_t d2 = SD_MUL(x - sx, x - sx) + SD_MUL(y - sy, y - sy);
                     if (d2 < best) { best = d2; bx = x; by = y; }
                 }
             }
@@ -296,7 +310,7 @@ SD_FN SdEdge sd_edge(int sx, int sy, int ax, int ay, int dir) {
     e.P = (float)(dir * e.vx);
     e.Q = (float)(dir * e.vy);
     e.invQ = e.Q != 0.f ? 1.0f / e.Q : 0.f;
-    e.a2 = (float)(e.vx * e.vx + e.vy * e.vy);
+    e.a2 = (float)(SD_MUL(e.vx, e.vx) + SD_MUL(e.vy, e.vy));
     return e;
 }
 
@@ -316,9 +330,9 @@ SD_FN void sd_best_set(SdBest& b, const SdEdge& e, int x, int y, float lam) {
 // lambda of the site (x, y), or false if it is not strictly on the searched side
 SD_FN bool sd_lambda(const SdEdge& e, int x, int y, float* lam) {
     const int cx = x - e.sx, cy = y - e.sy;
-    const int D = e.vx * cy - e.vy * cx;
+    const int D = SD_MUL(e.vx, cy) - SD_MUL(e.vy, cx);
     if (e.dir > 0 ? D <= 0 : D >= 0) return false;
-    const int N = cx * cx + cy * cy - (e.vx * cx + e.vy * cy);
+    const int N = SD_MUL(cx, cx) + SD_MUL(cy, cy) - (SD_MUL(e.vx, cx) + SD_MUL(e.vy, cy));
     *lam = (float)N * SD_RCP((float)(2 * (D < 0 ? -D : D)));
     return true;
 }
@@ -595,7 +609,7 @@ SD_FN int sd_walk(const SdGrid& g, int sx, int sy, bool fresh, int rax, int ray,
     if (!fresh) {
         mode = rhalf ? SD_MODE_HALF : (rdir > 0 ? SD_MODE_CCW : SD_MODE_CW);
         ax = sx + rax; ay = sy + ray; n0x = sx + rn0x; n0y = sy + rn0y;
-    } else if (sx + 1 < g.W && ((g.occ[sy * g.wpr + ((sx + 1) >> 5)] >> ((sx + 1) & 31)) & 1u)) {
+    } else if (sx + 1 < g.W && ((g.occ[SD_MUL(sy, g.wpr) + ((sx + 1) >> 5)] >> ((sx + 1) & 31)) & 1u)) {
         mode = SD_MODE_HALF;
         ax = n0x = sx + 1; ay = n0y = sy;
     } else {

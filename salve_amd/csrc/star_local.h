@@ -26,7 +26,7 @@ SD_FN uint32_t sdl_row32(const SdGrid& g, int y, int x0) {
     const bool yin = (unsigned)y < (unsigned)g.H;
     const int w0 = x0 >> 5, sh = x0 & 31;  // arithmetic shift: floor
     const bool in0 = yin & ((unsigned)w0 < (unsigned)g.wpr), in1 = yin & ((unsigned)(w0 + 1) < (unsigned)g.wpr);
-    const int base = (yin ? y : 0) * g.wpr;
+    const int base = SD_MUL(yin ? y : 0, g.wpr);
     uint32_t lo = g.occ[base + (in0 ? w0 : 0)], hi = g.occ[base + (in1 ? w0 + 1 : 0)];
     lo = in0 ? lo : 0u;
     hi = in1 ? hi : 0u;
@@ -41,7 +41,7 @@ SD_FN bool sdl_bit(const SdGrid& g, int x, int y) {
     // branch-free: an out-of-image probe reads word 0 and is masked (a guarded load costs an exec-mask round trip per probe)
     const bool in = (unsigned)x < (unsigned)g.W && (unsigned)y < (unsigned)g.H;
     const int xi = in ? x : 0, yi = in ? y : 0;
-    return in & (bool)((g.occ[yi * g.wpr + (xi >> 5)] >> (xi & 31)) & 1u);
+    return in & (bool)((g.occ[SD_MUL(yi, g.wpr) + (xi >> 5)] >> (xi & 31)) & 1u);
 }
 
 // Sites that need no walk at all.  If (x+1, y), (x-1, y) and (x, y+1) are sites, then every triangle that s OWNS (s its
