@@ -34,8 +34,9 @@ typedef enum {
     SALVE_ERR_WORKSPACE = -4
 } salve_status_t;
 
-#define SALVE_HIP_ABI_VERSION 4  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter,
-                                     salve_bev_workspace_init; 4: salve_bev_tile_pairs */
+#define SALVE_HIP_ABI_VERSION 5  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter;
+                                     4: salve_bev_tile_pairs; 5: panorama index (salve_bev_pano_index_*), the scatter stage writes the
+                                     sparse image into out_bev (no key image in memory, salve_bev_workspace_init is gone) */
 
 /* Device status word: an optional device int32 the caller zeroes once and passes to the launches below.  Kernels OR bits
  * into it when something went wrong that an int return value cannot report (the launch is asynchronous); the caller
@@ -43,6 +44,8 @@ typedef enum {
 #define SALVE_STATUS_WALK_FAILED 1 /* bev_densify: a Delaunay star did not close -- that render's image is incomplete */
 #define SALVE_STATUS_FP16_RANGE 2  /* resnet_forward: an activation exceeded the fp16 range and was saturated (no released
                                       checkpoint does this; a network without normalisation can) */
+#define SALVE_STATUS_BAD_HYPOTHESIS 4 /* bev scatter stage: a salve_bev_hyp_t row names a panorama outside [0, n_panos) or a surface
+                                         other than 0 / 1 -- that render is an empty image */
 
 /* Library / ABI version (SALVE_HIP_ABI_VERSION). */
 int salve_hip_version(void);
@@ -86,14 +89,21 @@ typedef struct {
     int32_t reserved;
 } salve_bev_hyp_t;
 
-/* Bytes of device workspace salve_bev_render_batch needs for n renders (0 on bad config). */
+/* Bytes of device workspace salve_bev_render_batch needs for n renders (0 on bad config).  The workspace needs no
+ * initialisation and carries nothing from one call to the next, except from a scatter-stage call to its densify call. */
 size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n);
-/* Must be called ONCE on a freshly allocated workspace before its first use (and again if the buffer was written by anything
- * else): zeroes the z-order key images of every render the buffer can hold.  The layout inside the buffer is a function of
- * `workspace_bytes` -- pass the SAME size to every call that uses the buffer; launches of any n up to its capacity share it.  The render calls do not clear them
- * per launch -- 1 MB of writes per render -- because the densify kernel leaves every key cell it read zeroed again; a
- * scatter whose densify never ran (an error in between) leaves the workspace dirty: initialise it again. */
-int salve_bev_workspace_init(const salve_bev_config_t* cfg, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Panorama index: the pose-INDEPENDENT part of the rasteriser's work, built once per set of panoramas (both surfaces are
+ * built) -- the counterpart of get_xyzrgb_from_depth's z filter (bev_rendering_utils.py:408-413), which the reference also
+ * evaluates once per panorama and surface, before any pose is applied (:431-446).  The panorama is cut into blocks of
+ * 16 x 4 pixels; the index holds, per block, the bounding box of the block's points that pass the surface's z filter, in
+ * the frame after the rotmat2d(-90) product (:443-446), 16 bytes per block and surface (180 KB per panorama at 1024 x 512).
+ * The render calls use it to visit, per 128 x 128 tile of the output image, only the blocks that can reach the tile under
+ * the render's pose.  It must be rebuilt when the depth maps change.
+ *   pano_index  device, 16-byte aligned, salve_bev_pano_index_bytes(cfg, n_panos) bytes */
+size_t salve_bev_pano_index_bytes(const salve_bev_config_t* cfg, int32_t n_panos);
+int salve_bev_pano_index_build(const salve_bev_config_t* cfg, const uint16_t* pano_depth, int32_t n_panos, const double* sphere,
+                               void* pano_index, size_t pano_index_bytes, void* stream);
 
 /*
  * Render n BEV texture maps.
@@ -101,6 +111,7 @@ int salve_bev_workspace_init(const salve_bev_config_t* cfg, int32_t n, void* wor
  *   pano_depth  device uint16 [P, pano_h, pano_w]          (.depth.png payload, millimetres)
  *   sphere      device double [2*pano_h + 2*pano_w]: r[v], zdir[v], cos(theta_u), sin(theta_u), computed on the
  *               host exactly as hohonet_pano_utils.get_uni_sphere_xyz does (salve/utils/hohonet_pano_utils.py:27-43)
+ *   pano_index  device: salve_bev_pano_index_build's output for exactly these P panoramas
  *   hyps        device salve_bev_hyp_t [n]
  *   out_bev     device uint32 [n, bev_h, bev_w]: final BEV image (after mask and np.flipud), 0x00BBGGRR
  *   dbg_img_xy  device int16 [n, (pano_h-2*crop_rows)*pano_w, 2] or NULL: BEV pixel (x, y) of every pano point,
@@ -115,28 +126,29 @@ int salve_bev_workspace_init(const salve_bev_config_t* cfg, int32_t n, void* wor
  *   status      device int32 status word or NULL (SALVE_STATUS_*)
  */
 int salve_bev_render_batch(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth,
-                           int32_t n_panos, const double* sphere, const salve_bev_hyp_t* hyps, int32_t n,
+                           int32_t n_panos, const double* sphere, const void* pano_index, const salve_bev_hyp_t* hyps, int32_t n,
                            uint32_t* out_bev, int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask,
                            int32_t* dbg_stats, int32_t* out_in_window, int32_t* status, void* workspace, size_t workspace_bytes,
                            void* stream);
 
-/* The two halves of salve_bev_render_batch as separate launches (same arguments, same workspace):
- * salve_bev_scatter fills the z-order key images (winning point index per pixel; the colours stay in pano_rgb, which
- * must remain valid until salve_bev_densify has run), salve_bev_densify turns them into BEV images.  Used by the
- * benchmark to time the dominant kernel on its own; render_batch == scatter followed by densify. */
+/* The two halves of salve_bev_render_batch as separate launches (same arguments, same workspace, same out_bev):
+ * salve_bev_scatter writes the SPARSE image into out_bev (the z-order winners' colours, :307-308, already flipped) and the
+ * occupancy bitmaps into the workspace; salve_bev_densify completes out_bev in place (interpolation + mask).  Used by the
+ * benchmark to time the stages on their own; render_batch == scatter followed by densify. */
 int salve_bev_scatter(const salve_bev_config_t* cfg, const uint8_t* pano_rgb, const uint16_t* pano_depth, int32_t n_panos,
-                      const double* sphere, const salve_bev_hyp_t* hyps, int32_t n, int16_t* dbg_img_xy, int32_t* out_in_window,
-                      void* workspace, size_t workspace_bytes, void* stream);
-int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, uint64_t* dbg_keys, uint8_t* dbg_mask,
+                      const double* sphere, const void* pano_index, const salve_bev_hyp_t* hyps, int32_t n, uint32_t* out_bev,
+                      int16_t* dbg_img_xy, uint64_t* dbg_keys, int32_t* out_in_window, int32_t* status, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, uint8_t* dbg_mask,
                       int32_t* dbg_stats, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Splat an explicit coloured point cloud -- the `xyzrgb` argument of render_bev_image (bev_rendering_utils.py:254-308):
  * xyz device double [n_points, 3] in the world frame, rgb device uint8 [n_points, 3] (the reference's float colours
- * already truncated to uint8, :307-308).  Fills key image 0 of the workspace; follow with salve_bev_densify(cfg, 1, ...),
- * which reads the winners' colours from `rgb` (keep it alive until then).
+ * already truncated to uint8, :307-308).  The scatter stage of ONE render: writes the sparse image into out_bev
+ * (uint32 [bev_h, bev_w]) and the bitmaps of render 0 into the workspace; follow with salve_bev_densify(cfg, 1, out_bev, ...).
  * n_in_window (device int32) receives the number of points inside the window (0 => render_bev_image returns None, :279). */
 int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, const uint8_t* rgb, int32_t n_points,
-                             int32_t* n_in_window, void* workspace, size_t workspace_bytes, void* stream);
+                             uint32_t* out_bev, int32_t* n_in_window, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Stand-alone forms of the three utilities the reference exposes next to the renderer.
  * salve_zorder_winners: zorder_utils.choose_elevated_repeated_vals (salve/utils/zorder_utils.py:10-83) -- x, y device
@@ -145,15 +157,15 @@ int salve_bev_scatter_points(const salve_bev_config_t* cfg, const double* xyz, c
  * salve_remove_hallucinated: interpolation_utils.remove_hallucinated_content (salve/utils/interpolation_utils.py:74-122) --
  *   sparse / interp / out device uint8 [H,W,3], scratch device uint8 [H*W].
  * salve_bev_keys_from_pixels: the input side of interpolation_utils.interp_dense_grid_from_sparse (:21-54) -- xy device
- *   int32 [n,2] (x, y) pixels, rgb device uint8 [n,3] (kept alive until the densify call, which reads the colours from
- *   it); fills key image 0; follow with salve_bev_densify(cfg, 1, ...) using cfg.out_flags = 3 (no flip, no mask) to
- *   obtain the interpolated image. */
+ *   int32 [n,2] (x, y) pixels, rgb device uint8 [n,3]; the scatter stage of one render (sparse image into out_bev, last index
+ *   wins); follow with salve_bev_densify(cfg, 1, out_bev, ...) using cfg.out_flags = 3 (no flip, no mask) to obtain the
+ *   interpolated image. */
 int salve_zorder_winners(const int32_t* x, const int32_t* y, const double* z, int32_t n, const double* planes, int32_t n_slices,
                          int32_t img_w, int32_t img_h, uint64_t* scratch, uint8_t* valid, void* stream);
 int salve_remove_hallucinated(const uint8_t* sparse, const uint8_t* interp, int32_t H, int32_t W, int32_t K, uint8_t* scratch,
                               uint8_t* out, void* stream);
-int salve_bev_keys_from_pixels(const salve_bev_config_t* cfg, const int32_t* xy, const uint8_t* rgb, int32_t n_points, void* workspace,
-                               size_t workspace_bytes, void* stream);
+int salve_bev_keys_from_pixels(const salve_bev_config_t* cfg, const int32_t* xy, const uint8_t* rgb, int32_t n_points, uint32_t* out_bev,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* Panorama ingest: n RGB uint8 images [n, src_h, src_w, 3] -> [n, dst_h, dst_w, 3] with the arithmetic of
  * cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_LINEAR), the call every panorama goes through before

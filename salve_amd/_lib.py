@@ -17,7 +17,7 @@ import os
 LIB_PATH = Path(os.environ.get("SALVE_HIP_LIB") or (Path(__file__).resolve().parent / "libsalve_hip.so"))
 
 SALVE_OK = 0
-EXPECTED_ABI = 4          # include/salve_hip.h: SALVE_HIP_ABI_VERSION
+EXPECTED_ABI = 5          # include/salve_hip.h: SALVE_HIP_ABI_VERSION
 TILE_F32_NCHW = 0
 TILE_F16_NHWC = 1
 
@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = (
     "salve_hip_version",
     "salve_last_error",
     "salve_bev_workspace_bytes",
-    "salve_bev_workspace_init",
+    "salve_bev_pano_index_bytes",
+    "salve_bev_pano_index_build",
     "salve_bev_render_batch",
     "salve_bev_scatter",
     "salve_bev_densify",
@@ -47,6 +48,7 @@ EXPORTED_SYMBOLS = (
 )
 STATUS_WALK_FAILED = 1
 STATUS_FP16_RANGE = 2
+STATUS_BAD_HYPOTHESIS = 4
 
 
 class BevConfig(ctypes.Structure):
@@ -96,21 +98,23 @@ def load() -> ctypes.CDLL:
     lib.salve_last_error.restype = ctypes.c_char_p
     lib.salve_bev_workspace_bytes.argtypes = [ctypes.POINTER(BevConfig), i32]
     lib.salve_bev_workspace_bytes.restype = sz
-    lib.salve_bev_workspace_init.argtypes = [ctypes.POINTER(BevConfig), i32, vp, sz, vp]
-    lib.salve_bev_workspace_init.restype = ctypes.c_int
-    lib.salve_bev_render_batch.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.salve_bev_pano_index_bytes.argtypes = [ctypes.POINTER(BevConfig), i32]
+    lib.salve_bev_pano_index_bytes.restype = sz
+    lib.salve_bev_pano_index_build.argtypes = [ctypes.POINTER(BevConfig), vp, i32, vp, vp, sz, vp]
+    lib.salve_bev_pano_index_build.restype = ctypes.c_int
+    lib.salve_bev_render_batch.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.salve_bev_render_batch.restype = ctypes.c_int
-    lib.salve_bev_scatter.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, i32, vp, vp, vp, sz, vp]
+    lib.salve_bev_scatter.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.salve_bev_scatter.restype = ctypes.c_int
-    lib.salve_bev_densify.argtypes = [ctypes.POINTER(BevConfig), i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.salve_bev_densify.argtypes = [ctypes.POINTER(BevConfig), i32, vp, vp, vp, vp, vp, sz, vp]
     lib.salve_bev_densify.restype = ctypes.c_int
-    lib.salve_bev_scatter_points.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, sz, vp]
+    lib.salve_bev_scatter_points.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, vp, sz, vp]
     lib.salve_bev_scatter_points.restype = ctypes.c_int
     lib.salve_zorder_winners.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, vp]
     lib.salve_zorder_winners.restype = ctypes.c_int
     lib.salve_remove_hallucinated.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     lib.salve_remove_hallucinated.restype = ctypes.c_int
-    lib.salve_bev_keys_from_pixels.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, sz, vp]
+    lib.salve_bev_keys_from_pixels.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, sz, vp]
     lib.salve_bev_keys_from_pixels.restype = ctypes.c_int
     lib.salve_layout_rasterise.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp]
     lib.salve_layout_rasterise.restype = ctypes.c_int
@@ -149,6 +153,8 @@ def check_status_word(word: int, what: str) -> None:
     if word & STATUS_FP16_RANGE:
         raise SalveHipError(f"{what}: an activation of the verifier exceeded the fp16 range and was saturated; the logits are "
                             "not those of the fp32 network (a network without trained normalisation statistics does this)")
+    if word & STATUS_BAD_HYPOTHESIS:
+        raise SalveHipError(f"{what}: a render row names a panorama outside the uploaded batch (or an unknown surface); its image is empty")
     if word:
         raise SalveHipError(f"{what}: device status word {word:#x}")
 

@@ -158,12 +158,12 @@ class RenderVerifyPipeline:
         e0.record()
         return e0, e1
 
-    def _scatter_chunk(self, prepared, lo: int, n: int, slot: int, timers=None) -> None:
+    def _scatter_chunk(self, prepared, lo: int, n: int, buf: int, slot: int, timers=None) -> None:
         S = len(self.surfaces)
         self.ras.ws_slot = slot
         _, e1 = self._timed(timers, n * S, "scatter")
         with tracing.range("salve.scatter"):
-            self.ras.scatter(self.pano_rgb, self.pano_depth, prepared["rows"][lo * S * _lib.HYP_DTYPE.itemsize:], n * S,
+            self.ras.scatter(self.pano_rgb, self.pano_depth, prepared["rows"][lo * S * _lib.HYP_DTYPE.itemsize:], n * S, self.bevs[buf],
                              in_window=prepared["in_window"][lo * S:(lo + n) * S])
         if e1 is not None:
             e1.record()
@@ -224,8 +224,11 @@ class RenderVerifyPipeline:
                     ss.wait_event(prepared["ready"])
                     ss.wait_event(self._panos_ready)
                 if self._densified[slot] is not None:
-                    ss.wait_event(self._densified[slot])      # the densify that read this workspace slot is done
-                self._scatter_chunk(prepared, lo, n, slot, timers)
+                    # the densify + tile kernels that used this workspace slot are done -- and with them the last reader of the
+                    # BEV buffer the scatter is about to write its sparse images into (buffer set == slot whenever the
+                    # scatter has a stream of its own; otherwise scatter and densify share a stream)
+                    ss.wait_event(self._densified[slot])
+                self._scatter_chunk(prepared, lo, n, buf, slot, timers)
                 scattered = torch.cuda.Event()
                 scattered.record(ss)
             with torch.cuda.stream(rs):

@@ -113,17 +113,11 @@ class BevRasteriser:
         self.coef_x = torch.from_numpy(linear_resize_taps(resize, self.bev_hw[1])).to(self.device)
         self.lut = torch.from_numpy(normalisation_lut()).to(self.device)
         self._ws_slots = {}   # workspaces by slot: a caller that keeps two batches in flight alternates `ws_slot`
-        self._dirty = {}      # slot -> True while key images may hold keys no densify has consumed (see _keys_written)
         self.ws_slot = 0
 
     # ------------------------------------------------------------------ helpers
     def _stream(self) -> ctypes.c_void_p:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-
-    def _init_workspace(self, ws: torch.Tensor, n: int) -> None:
-        with torch.cuda.device(self.device):
-            st = self.lib.salve_bev_workspace_init(ctypes.byref(self.cfg), n, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
-        _lib.check(st, "salve_bev_workspace_init")
 
     def _workspace(self, n: int) -> torch.Tensor:
         need = self.lib.salve_bev_workspace_bytes(ctypes.byref(self.cfg), n)
@@ -132,27 +126,32 @@ class BevRasteriser:
         ws = self._ws_slots.get(self.ws_slot)
         if ws is None or ws.numel() < need:
             ws = self._ws_slots[self.ws_slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
-            # key images zeroed once per buffer: the launches keep them clean (salve_hip.h: salve_bev_workspace_init)
-            self._init_workspace(ws, n)
-            self._ws_cap = getattr(self, "_ws_cap", {})
-            self._ws_cap[self.ws_slot] = n
-            self._dirty[self.ws_slot] = False
         return ws
 
-    def _keys_written(self, n: int) -> torch.Tensor:
-        """The workspace of the current slot for a launch that WRITES key images.  The key images are clean only while every
-        scatter is followed by its densify (which re-zeroes what it read): if the previous scatter of this slot never reached
-        its densify -- an exception between the two launches -- the stale keys would show up as spurious sites of a later
-        render, silently.  The slot is therefore marked dirty here and clean by `_keys_consumed`; a scatter that finds it
-        dirty initialises the workspace again first (salve_hip.h: "initialise it again")."""
-        ws = self._workspace(n)
-        if self._dirty.get(self.ws_slot):
-            self._init_workspace(ws, self._ws_cap[self.ws_slot])
-        self._dirty[self.ws_slot] = True
-        return ws
+    def pano_index(self, pano_depth: torch.Tensor) -> torch.Tensor:
+        """The pose-independent panorama index of these depth maps (include/salve_hip.h: salve_bev_pano_index_build), built
+        on first use on the current stream and kept with the tensor OBJECT: it lives as long as the tensor does, a slice or a
+        copy builds its own, and a caller that overwrites the depth maps in place calls `drop_pano_index` first."""
+        idx = getattr(pano_depth, "_salve_pano_index", None)
+        P = int(pano_depth.shape[0])
+        if idx is not None and idx[1] == (pano_depth.data_ptr(), P):
+            return idx[0]
+        assert pano_depth.is_contiguous() and tuple(pano_depth.shape[1:]) == self.pano_hw and pano_depth.element_size() == 2
+        nbytes = self.lib.salve_bev_pano_index_bytes(ctypes.byref(self.cfg), P)
+        if nbytes == 0:
+            _lib.check(-1, "salve_bev_pano_index_bytes")
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_pano_index_build(ctypes.byref(self.cfg), ctypes.c_void_p(pano_depth.data_ptr()), P,
+                                                     ctypes.c_void_p(self.sphere.data_ptr()), ctypes.c_void_p(buf.data_ptr()), nbytes, self._stream())
+        _lib.check(st, "salve_bev_pano_index_build")
+        pano_depth._salve_pano_index = (buf, (pano_depth.data_ptr(), P))
+        return buf
 
-    def _keys_consumed(self) -> None:
-        self._dirty[self.ws_slot] = False
+    @staticmethod
+    def drop_pano_index(pano_depth: torch.Tensor) -> None:
+        if hasattr(pano_depth, "_salve_pano_index"):
+            del pano_depth._salve_pano_index
 
     def upload_panos(self, rgb: np.ndarray, depth: np.ndarray) -> Tuple[torch.Tensor, torch.Tensor]:
         """rgb uint8 [P,H,W,3], depth uint16 [P,H,W] (host) -> device tensors (depth carried as int16 bits)."""
@@ -180,75 +179,79 @@ class BevRasteriser:
             dbg.mask = torch.empty((n, Hb, Wb), dtype=torch.uint8, device=self.device)
             dbg.stats = torch.zeros((n, 8), dtype=torch.int32, device=self.device)
             dbg.in_window = torch.zeros(n, dtype=torch.int32, device=self.device)
-        ws = self._keys_written(n)
+        ws = self._workspace(n)
+        index = self.pano_index(pano_depth)
         P = int(pano_rgb.shape[0])
         ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
         with torch.cuda.device(self.device):
             st = self.lib.salve_bev_render_batch(
-                ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), P, ptr(self.sphere), ptr(hyps_dev), n,
+                ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), P, ptr(self.sphere), ptr(index), ptr(hyps_dev), n,
                 ptr(out_bev), ptr(dbg.img_xy), ptr(dbg.keys), ptr(dbg.mask), ptr(dbg.stats), ptr(dbg.in_window), status.ptr(self.device),
                 ptr(ws), ws.numel(), self._stream(),
             )
         _lib.check(st, "salve_bev_render_batch")
-        self._keys_consumed()
         return out_bev, dbg
 
-    def scatter(self, pano_rgb: torch.Tensor, pano_depth: torch.Tensor, hyps_dev: torch.Tensor, n: int,
+    def scatter(self, pano_rgb: torch.Tensor, pano_depth: torch.Tensor, hyps_dev: torch.Tensor, n: int, out_bev: torch.Tensor,
                 in_window: Optional[torch.Tensor] = None) -> None:
-        """First half of `render`: z-order key images into the workspace.  `in_window` (int32 [n]) receives the number of
-        points inside the window per render (0 => the reference writes no tile, bev_rendering_utils.py:279, 623-627)."""
-        ws = self._keys_written(n)
+        """First half of `render`: the sparse images (z-order winners' colours) into `out_bev`, the occupancy bitmaps into the
+        workspace.  `in_window` (int32 [n]) receives the number of points inside the window per render (0 => the reference
+        writes no tile, bev_rendering_utils.py:279, 623-627)."""
+        ws = self._workspace(n)
+        index = self.pano_index(pano_depth)
         with torch.cuda.device(self.device):
             st = self.lib.salve_bev_scatter(
                 ctypes.byref(self.cfg), ctypes.c_void_p(pano_rgb.data_ptr()), ctypes.c_void_p(pano_depth.data_ptr()),
-                int(pano_rgb.shape[0]), ctypes.c_void_p(self.sphere.data_ptr()), ctypes.c_void_p(hyps_dev.data_ptr()), n, None,
-                ctypes.c_void_p(0 if in_window is None else in_window.data_ptr()),
+                int(pano_rgb.shape[0]), ctypes.c_void_p(self.sphere.data_ptr()), ctypes.c_void_p(index.data_ptr()),
+                ctypes.c_void_p(hyps_dev.data_ptr()), n, ctypes.c_void_p(out_bev.data_ptr()), None, None,
+                ctypes.c_void_p(0 if in_window is None else in_window.data_ptr()), status.ptr(self.device),
                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
         _lib.check(st, "salve_bev_scatter")
 
     def densify(self, n: int, out_bev: torch.Tensor) -> torch.Tensor:
-        """Second half of `render`: key images -> BEV images."""
+        """Second half of `render`: completes the sparse images of `scatter` in place (same `out_bev`, same workspace slot)."""
         ws = self._workspace(n)
         with torch.cuda.device(self.device):
-            st = self.lib.salve_bev_densify(ctypes.byref(self.cfg), n, ctypes.c_void_p(out_bev.data_ptr()), None, None, None,
+            st = self.lib.salve_bev_densify(ctypes.byref(self.cfg), n, ctypes.c_void_p(out_bev.data_ptr()), None, None,
                                             status.ptr(self.device), ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
         _lib.check(st, "salve_bev_densify")
-        self._keys_consumed()
         return out_bev
 
     def render_counted(self, pano_rgb: torch.Tensor, pano_depth: torch.Tensor, hyps_dev: torch.Tensor, n: int,
                        out_bev: torch.Tensor, counts: torch.Tensor) -> None:
         """`render` that also reports, per render, how many points fell inside the window (int32 [n])."""
-        ws = self._keys_written(n)
+        ws = self._workspace(n)
+        index = self.pano_index(pano_depth)
         ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
         with torch.cuda.device(self.device):
             st = self.lib.salve_bev_render_batch(
-                ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), int(pano_rgb.shape[0]), ptr(self.sphere), ptr(hyps_dev), n,
+                ctypes.byref(self.cfg), ptr(pano_rgb), ptr(pano_depth), int(pano_rgb.shape[0]), ptr(self.sphere), ptr(index), ptr(hyps_dev), n,
                 ptr(out_bev), None, None, None, None, ptr(counts), status.ptr(self.device), ptr(ws), ws.numel(), self._stream())
         _lib.check(st, "salve_bev_render_batch")
-        self._keys_consumed()
 
     def render_points(self, xyz: np.ndarray, rgb_u8: np.ndarray):
         """One BEV image from an explicit world-frame point cloud (host arrays).  Returns (int32 [1,H,W], n_in_window)."""
         xyz_d = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float64)).to(self.device)
         rgb_d = torch.from_numpy(np.ascontiguousarray(rgb_u8, dtype=np.uint8)).to(self.device)
         cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
-        ws = self._keys_written(1)
+        Hb, Wb = self.bev_hw
+        bev = torch.empty((1, Hb, Wb), dtype=torch.int32, device=self.device)
+        ws = self._workspace(1)
         with torch.cuda.device(self.device):
             st = self.lib.salve_bev_scatter_points(ctypes.byref(self.cfg), ctypes.c_void_p(xyz_d.data_ptr()), ctypes.c_void_p(rgb_d.data_ptr()),
-                                                   int(xyz_d.shape[0]), ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                                                   ws.numel(), self._stream())
+                                                   int(xyz_d.shape[0]), ctypes.c_void_p(bev.data_ptr()), ctypes.c_void_p(cnt.data_ptr()),
+                                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
         _lib.check(st, "salve_bev_scatter_points")
-        Hb, Wb = self.bev_hw
-        bev = self.densify(1, torch.empty((1, Hb, Wb), dtype=torch.int32, device=self.device))
+        self.densify(1, bev)
         return bev, int(cnt.item())
 
-    def keys_from_pixels(self, xy: torch.Tensor, rgb: torch.Tensor) -> None:
-        """Key image of ONE render from explicit integer pixels (int32 [n, 2]) and colours (uint8 [n, 3]); follow with densify(1)."""
-        ws = self._keys_written(1)
+    def keys_from_pixels(self, xy: torch.Tensor, rgb: torch.Tensor, out_bev: torch.Tensor) -> None:
+        """Sparse image of ONE render from explicit integer pixels (int32 [n, 2]) and colours (uint8 [n, 3]) into `out_bev`
+        (int32 [1, H, W]); follow with densify(1, out_bev)."""
+        ws = self._workspace(1)
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         with torch.cuda.device(self.device):
-            st = self.lib.salve_bev_keys_from_pixels(ctypes.byref(self.cfg), p(xy), p(rgb), int(xy.shape[0]), p(ws), ws.numel(), self._stream())
+            st = self.lib.salve_bev_keys_from_pixels(ctypes.byref(self.cfg), p(xy), p(rgb), int(xy.shape[0]), p(out_bev), p(ws), ws.numel(), self._stream())
         _lib.check(st, "salve_bev_keys_from_pixels")
 
     def check(self, what: str) -> None:

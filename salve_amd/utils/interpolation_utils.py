@@ -42,8 +42,9 @@ def interp_dense_grid_from_sparse(bev_img: np.ndarray, points: np.ndarray, rgb_v
     ras.cfg.out_flags = 3  # no flip, no mask: the plain interpolant
     xy = torch.from_numpy(np.ascontiguousarray(points[:, :2], dtype=np.int32)).to(dev)
     rgb = torch.from_numpy(np.ascontiguousarray(rgb_values).astype(np.uint8)).to(dev)
-    ras.keys_from_pixels(xy, rgb)
-    bev = ras.densify(1, torch.empty((1, grid_h, grid_w), dtype=torch.int32, device=dev))
+    bev = torch.empty((1, grid_h, grid_w), dtype=torch.int32, device=dev)
+    ras.keys_from_pixels(xy, rgb, bev)
+    ras.densify(1, bev)
     out = ras.export_u8(bev)[0].cpu().numpy()
     ras.check("interp_dense_grid_from_sparse")   # a star walk that did not close = an incomplete interpolant: never silently
     bev_img[...] = out

@@ -131,7 +131,7 @@ def test_tile_pairs_equal_two_tile_calls(setup):
     """salve_bev_tile_pairs (both tiles of an early-fusion pair per thread, whole-pixel stores, padding zeroed) against two
     salve_bev_tiles calls: bit for bit, for one surface (8 channels) and two (16), either channel order, a dirty buffer."""
     ras, panos, d_rgb, d_depth, hyp = setup
-    h = pack_hypotheses([0, 1, 2, 3], [0, 0, 1, 1], hyp.R[:4], hyp.t[:4], [1, 0, 1, 0])
+    h = pack_hypotheses([0, 1, 0, 1], [0, 0, 1, 1], hyp.R[:4], hyp.t[:4], [1, 0, 1, 0])
     bev, _ = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), 4)
     other = bev.flip(0).contiguous()     # a second image array (the pipeline's cached identity renders)
     for out_c, groups in ((8, 1), (16, 2)):
@@ -164,11 +164,25 @@ def test_degenerate_inputs(setup):
     assert (dbg.img_xy == -1).all()
 
 
+def test_a_row_that_names_a_missing_panorama_is_reported(setup):
+    """A render row whose pano_idx lies outside the uploaded batch: an empty image and SALVE_STATUS_BAD_HYPOTHESIS, never a read
+    beyond the buffers."""
+    ras, panos, d_rgb, d_depth, hyp = setup
+    h = pack_hypotheses([0, 7, 1], [0, 0, 2], hyp.R[:3], hyp.t[:3], [1, 1, 1])      # panorama 7 of 2; surface 2
+    ras.check("before")
+    bev, _ = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), 3)
+    torch.cuda.synchronize()
+    assert bev[0].any() and not bev[1].any() and not bev[2].any()
+    with pytest.raises(_lib.SalveHipError, match="panorama outside"):
+        ras.check("test")
+    ras.check("after")   # the word was reset
+
+
 def test_bad_arguments_are_reported(setup):
     ras, panos, d_rgb, d_depth, hyp = setup
     import ctypes
 
-    st = ras.lib.salve_bev_render_batch(ctypes.byref(ras.cfg), None, None, 1, None, None, 1, None, None, None, None, None, None, None, None, 0, None)
+    st = ras.lib.salve_bev_render_batch(ctypes.byref(ras.cfg), None, None, 1, None, None, None, 1, None, None, None, None, None, None, None, None, 0, None)
     assert st == -1 and b"null" in ras.lib.salve_last_error()
     with pytest.raises(_lib.SalveHipError):
         ras.tiles(torch.zeros(1, device=ras.device, dtype=torch.int32), ras.upload_tile_jobs([0], [0], [0]), 1,
@@ -360,19 +374,41 @@ def test_gpu_output_against_the_reference_small_geometry_renders():
 
 
 def test_render_after_an_aborted_scatter_is_exact(setup):
-    """The key images are clean only while every scatter is followed by its densify.  A scatter whose densify never ran (an
-    exception between the two launches) leaves keys behind; BevRasteriser marks the workspace slot dirty at the scatter and
-    initialises it again before the next one -- the next render must be the quiet render's, bit for bit."""
+    """Nothing is carried from one launch to the next (until round 3 the key images in the workspace were: a scatter whose
+    densify never ran left keys behind).  A scatter stage whose densify never runs -- an exception between the two launches --
+    followed by a render into the same workspace and another image buffer: the quiet render's images, bit for bit."""
     ras, panos, d_rgb, d_depth, hyp = setup
     n = 4
     ha = ras.upload_hypotheses(pack_hypotheses(hyp.i1[:n], np.zeros(n), hyp.R[:n], hyp.t[:n], np.ones(n)))
     hb = ras.upload_hypotheses(pack_hypotheses(hyp.i1[n:2 * n], np.zeros(n), hyp.R[n:2 * n], hyp.t[n:2 * n], np.ones(n)))
     quiet, _ = ras.render(d_rgb, d_depth, hb, n)
     quiet = quiet.clone()
-    ras.scatter(d_rgb, d_depth, ha, n)          # ... and the caller "fails" before densify
-    assert ras._dirty[ras.ws_slot]
+    scratch = torch.empty_like(quiet)
+    ras.scatter(d_rgb, d_depth, ha, n, scratch)          # ... and the caller "fails" before densify
     again, _ = ras.render(d_rgb, d_depth, hb, n)
     torch.cuda.synchronize()
-    assert not ras._dirty[ras.ws_slot]
-    assert torch.equal(again, quiet), "stale keys of the aborted scatter leaked into the next render"
+    assert torch.equal(again, quiet), "state of the aborted scatter leaked into the next render"
     ras.check("test_render_after_an_aborted_scatter_is_exact")
+
+
+def test_scatter_then_densify_equals_render_and_the_sparse_image_is_the_oracles(setup):
+    """The two stages as separate launches (the benchmark's form): the scatter stage alone leaves the SPARSE image
+    (bev_rendering_utils.py:307-308, flipped) in the buffer, the densify stage completes it to the image of `render`."""
+    ras, panos, d_rgb, d_depth, hyp = setup
+    n = 3
+    rows = [(int(hyp.i1[k]), "floor" if k % 2 == 0 else "ceiling", hyp.R[k], hyp.t[k], 1) for k in range(n)]
+    hd = ras.upload_hypotheses(pack_hypotheses([r[0] for r in rows], [0 if r[1] == "floor" else 1 for r in rows], np.stack([r[2] for r in rows]),
+                                               np.stack([r[3] for r in rows]), [1] * n))
+    whole, _ = ras.render(d_rgb, d_depth, hd, n)
+    whole = whole.clone()
+    buf = torch.empty_like(whole)
+    counts = torch.zeros(n, dtype=torch.int32, device=ras.device)
+    ras.scatter(d_rgb, d_depth, hd, n, buf, in_window=counts)
+    sparse = ras.export_u8(buf).cpu().numpy()
+    ras.densify(n, buf)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, whole)
+    for k, (pi, surface, R, t, ap) in enumerate(rows):
+        res, _ = oracle_render(panos, pi, surface, R, t, ap)
+        assert np.array_equal(sparse[k], res["sparse"][::-1]), f"render {k}: sparse image"
+        assert int(counts[k]) == res["img_xy"].shape[0]

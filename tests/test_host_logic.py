@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.salve_hip_version() == 4
+    assert lib.salve_hip_version() == _lib.EXPECTED_ABI == int(re.search(r"#define SALVE_HIP_ABI_VERSION (\d+)", header).group(1))
     assert lib.salve_last_error() is not None
 
 
