@@ -18,11 +18,23 @@
 //                           point cloud / explicit pixels: one render, not on the benchmark's path).
 #pragma once
 
-constexpr int SPLAT_THREADS = 512;
+#ifndef SPLAT_THREADS_N
+#define SPLAT_THREADS_N 768
+#endif
+constexpr int SPLAT_THREADS = SPLAT_THREADS_N;
 constexpr int TILE_W = 128, TILE_H = 128;   // output tile whose keys live in LDS
+constexpr int TILE_LD = TILE_W + 1;         // row stride of the key tile in LDS: with 128 every pixel column would be one bank
 constexpr int TILE_WORDS = TILE_W / 32;     // bitmap words per tile row
 constexpr int BLK_W = 16, BLK_H = 4;        // panorama block = one wavefront: lane -> (row lane >> 4, column lane & 15)
-constexpr int SPLAT_BATCH = 4;              // blocks a wavefront keeps in flight (loads of all of them issued before any is used)
+#ifndef SPLAT_BATCH_N
+#define SPLAT_BATCH_N 4
+#endif
+constexpr int SPLAT_BATCH = SPLAT_BATCH_N;  // blocks a wavefront keeps in flight (loads of all of them issued before any is used)
+// Timing-only builds (tools/splat_ablation.sh; wrong images): SPLAT_ABL bit 0 = cull only (no point is processed),
+// bit 1 = no block loop at all, bit 2 = no emission (nothing is written), bit 3 = no LDS atomic, bit 4 = no loads (made-up depth / table values).
+#ifndef SPLAT_ABL
+#define SPLAT_ABL 0
+#endif
 
 // Block grid of a panorama: nbr block rows x (gpr groups of 64 block columns); entry (br, g, j) is block column 64 g + j.
 struct PanoGrid {
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256) void bev_pano_index_kernel(DevCfg c, PanoGrid 
 
 // LDS of the splat / emit kernels: key tile, the tile's bitmap words, two counters.
 struct SplatLds {
-    uint32_t tile[TILE_H * TILE_W];
+    uint32_t tile[TILE_H * TILE_LD];
     uint32_t bm[2][TILE_H][TILE_WORDS];
     int next_group, in_window;
 };
@@ -111,12 +123,15 @@ __device__ __forceinline__ void emit_tile(const DevCfg& c, SplatLds& s, const ui
                                           int tx0, int ty0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = SPLAT_THREADS >> 6;
     const int flip = (c.out_flags & 1) ? -1 : c.H - 1;
-    for (int r0 = wave * 2; r0 < TILE_H; r0 += nwaves * 2) {   // two rows x two 64-pixel segments per step: four gathers in flight
-        uint32_t key[4], col[4];
+    // EMIT_ROWS rows x two 64-pixel segments per step: all keys, then all colour gathers (a fifth of the pixels hold a winner),
+    // then the stores -- the step is one trip to memory, not one per row
+    constexpr int EMIT_ROWS = 4, NQ = 2 * EMIT_ROWS;
+    for (int r0 = wave * EMIT_ROWS; r0 < TILE_H; r0 += nwaves * EMIT_ROWS) {
+        uint32_t key[NQ], col[NQ];
 #pragma unroll
-        for (int q = 0; q < 4; q++) key[q] = s.tile[(r0 + (q >> 1)) * TILE_W + (q & 1) * 64 + lane];
+        for (int q = 0; q < NQ; q++) key[q] = s.tile[(r0 + (q >> 1)) * TILE_LD + (q & 1) * 64 + lane];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NQ; q++) {
             col[q] = 0u;
             if (key[q] != 0u) {   // the winner's colour from its source array (:307-308: rgb * 255 truncated == the source uint8)
                 const uint8_t* cs = colours + 3 * (size_t)(key[q] & KEY_INDEX_MASK);
@@ -124,7 +139,7 @@ __device__ __forceinline__ void emit_tile(const DevCfg& c, SplatLds& s, const ui
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NQ; q++) {
             const int row = r0 + (q >> 1), x = tx0 + (q & 1) * 64 + lane, y = ty0 + row;
             if (x < c.W && y < c.H) {
                 const uint32_t p = (uint32_t)((flip >= 0 ? flip - y : y) * c.W + x);
@@ -153,7 +168,7 @@ __device__ __forceinline__ void emit_tile(const DevCfg& c, SplatLds& s, const ui
 }
 
 template <bool DEV>
-__global__ __launch_bounds__(SPLAT_THREADS, 4) void bev_splat_kernel(
+__global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_kernel(
     DevCfg c, PanoGrid pg, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, const double* __restrict__ sphere,
     const salve_bev_hyp_t* __restrict__ hyps, const float4* __restrict__ boxes, const int* __restrict__ range_lo, const int* __restrict__ range_hi,
     uint32_t* __restrict__ bev_all, uint32_t* __restrict__ bitmaps_all, int32_t* __restrict__ in_window, int16_t* __restrict__ dbg_xy_arg,
@@ -174,7 +189,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, 4) void bev_splat_kernel(
     const int tx0 = (t % tiles_x) * TILE_W, ty0 = (t / tiles_x) * TILE_H;
     const int tw = min(TILE_W, c.W - tx0), th = min(TILE_H, c.H - ty0);
 
-    for (int i = tid; i < TILE_H * TILE_W / 4; i += SPLAT_THREADS) reinterpret_cast<uint4*>(s.tile)[i] = make_uint4(0u, 0u, 0u, 0u);
+    static_assert((TILE_H * TILE_LD) % 4 == 0, "the key tile is zeroed in 16-byte pieces, the bitmap words behind it are read in such");
+    for (int i = tid; i < TILE_H * TILE_LD / 4; i += SPLAT_THREADS) reinterpret_cast<uint4*>(s.tile)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) { s.next_group = 0; s.in_window = 0; }
 
     // The tile in the posed frame: pixel index rint((x + tx) * scale) in [tx0, tx0 + tw) <=> x in [(tx0 - .5) / scale - tx,
@@ -203,11 +219,11 @@ __global__ __launch_bounds__(SPLAT_THREADS, 4) void bev_splat_kernel(
     const double zlo = c.zlo[h.surface], zhi = c.zhi[h.surface];
     const double R00 = (double)h.R[0], R01 = (double)h.R[1], R10 = (double)h.R[2], R11 = (double)h.R[3];
     const double ptx = (double)(h.t[0] * 1.5f), pty = (double)(h.t[1] * 1.5f);   // float32 product, then widened (:451)
-    const uint16_t* dpano = depth + (size_t)h.pano_idx * c.pano_h * c.pano_w;
+    const uint16_t* dpano = depth + (bad_row ? (size_t)0 : (size_t)h.pano_idx * c.pano_h * c.pano_w);
     int my_in_window = 0;
     __syncthreads();
 
-    for (;;) {
+    for (; !(SPLAT_ABL & 2);) {
         // a wavefront takes one group of 64 blocks at a time (dynamic: the groups that reach a tile are few and uneven)
         int g = 0;
         if (lane == 0) g = atomicAdd(&s.next_group, 1);
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, 4) void bev_splat_kernel(
             hit = hit && px + qx + slack >= wx0 && px - qx - slack <= wx1 && py + qy + slack >= wy0 && py - qy - slack <= wy1;
         }
         unsigned long long m = __ballot(hit);
+        if (SPLAT_ABL & 1) { my_in_window += (int)__popcll(m); continue; }
         if (m == 0ull) continue;
         const int br = g / pg.gpr, gc = g - br * pg.gpr;
         const int vr = br * BLK_H + (lane >> 4);                 // row of this lane's pixel in every block of the group
@@ -245,39 +262,44 @@ __global__ __launch_bounds__(SPLAT_THREADS, 4) void bev_splat_kernel(
                     ok[k] = row_ok && u[k] < c.pano_w;
                 }
             }
+            // (32-bit element offsets from wave-uniform bases: one address register per load instead of a 64-bit sum)
+            const uint32_t vrow = (uint32_t)v * (uint32_t)c.pano_w;
 #pragma unroll
             for (int k = 0; k < SPLAT_BATCH; k++) {
-                dep[k] = 0u; ctu[k] = 0.0; stu[k] = 0.0;
-                if (ok[k]) { dep[k] = dpano[(size_t)v * c.pano_w + u[k]]; ctu[k] = ct[u[k]]; stu[k] = st[u[k]]; }
+                const uint32_t uu = ok[k] ? (uint32_t)u[k] : 0u;   // lanes without a pixel read pixel (v, 0): valid memory, result unused
+                if (SPLAT_ABL & 16) { dep[k] = 1500u + (uu & 255u); ctu[k] = 0.001 * (double)(uu & 511u); stu[k] = 0.3; }
+                else { dep[k] = dpano[vrow + uu]; ctu[k] = ct[uu]; stu[k] = st[uu]; }
             }
 #pragma unroll
             for (int k = 0; k < SPLAT_BATCH; k++) {
-                if (!ok[k]) continue;
+                // branch-free up to the stores: a wavefront executes every path any of its lanes takes anyway
                 const BackProj b = back_project(c, dep[k], rv, zv, ctu[k], stu[k]);
-                if (!(b.z > zlo && b.z <= zhi)) continue;
+                bool live = ok[k] && b.z > zlo && b.z <= zhi;
                 double x1 = b.x1, y1 = b.y1;
-                if (h.apply_pose) {   // xy @ R32.T + t32 * 1.5 (:448-451), OpenBLAS' FMA order
+                if (h.apply_pose) {   // (wave-uniform) xy @ R32.T + t32 * 1.5 (:448-451), OpenBLAS' FMA order
                     const double x2 = fma(y1, R01, x1 * R00) + ptx;
                     const double y2 = fma(y1, R11, x1 * R10) + pty;
                     x1 = x2; y1 = y2;
                 }
-                if (!(c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax)) continue;
+                live = live && c.xmin <= x1 && x1 <= c.xmax && c.ymin <= y1 && y1 <= c.ymax;
                 // bevimg_Sim2_world.transform_from: (p @ I.T + t) * s, then np.round (half to even); the identity product is exact
                 // up to the sign of a zero, which the rounding erases
-                const int ix = (int)rint((x1 + c.tx) * c.scale);
-                const int iy = (int)rint((y1 + c.ty) * c.scale);
+                const int ix = live ? (int)rint((x1 + c.tx) * c.scale) : -1;
+                const int iy = live ? (int)rint((y1 + c.ty) * c.scale) : -1;
                 // the tile that owns the point (counts it, reports it): the one its clamped index falls into
                 const int ox = min(max(ix, 0), c.W - 1) - tx0, oy = min(max(iy, 0), c.H - 1) - ty0;
-                if (ox < 0 || ox >= TILE_W || oy < 0 || oy >= TILE_H) continue;
-                my_in_window++;
-                const int p = vr * c.pano_w + u[k];   // raster index in the cropped panorama
-                if (DEV && dbg_xy) {
+                live = live && (unsigned)ox < (unsigned)TILE_W && (unsigned)oy < (unsigned)TILE_H;
+                my_in_window += live ? 1 : 0;
+                const uint32_t p = (uint32_t)vr * (uint32_t)c.pano_w + (uint32_t)u[k];   // raster index in the cropped panorama
+                if (DEV && dbg_xy && live) {
                     int16_t* o = dbg_xy + ((size_t)rid * c.npts + p) * 2;
                     o[0] = (int16_t)ix; o[1] = (int16_t)iy;
                 }
                 const double zs = floor(b.z) - c.zmin;   // unit slices from an integer z_min: exact (zorder_utils.py:49-59)
-                if (zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H)
-                    atomicMax(&s.tile[(iy - ty0) * TILE_W + (ix - tx0)], ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | (uint32_t)p);
+                const bool splat = live && zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H;
+                if (SPLAT_ABL & 8) my_in_window += (int)zs + ix;
+                else if (splat)
+                    atomicMax(&s.tile[(iy - ty0) * TILE_LD + (ix - tx0)], ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | p);
             }
         }
     }
@@ -285,6 +307,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, 4) void bev_splat_kernel(
     if (lane == 0 && my_in_window) atomicAdd(&s.in_window, my_in_window);
     __syncthreads();
     if (tid == 0 && in_window && s.in_window) atomicAdd(in_window + rid, s.in_window);
+    if (SPLAT_ABL & 4) return;
     const uint8_t* colours = rgb + ((size_t)h.pano_idx * c.pano_h + c.crop_rows) * c.pano_w * 3;
     emit_tile<DEV>(c, s, colours, bev_all + (size_t)rid * c.H * c.W, bitmaps_all + (size_t)rid * 2 * ntiles * TILE_H * TILE_WORDS,
                    dbg_keys ? dbg_keys + (size_t)rid * c.H * c.W : nullptr, t, ntiles, tx0, ty0);
@@ -298,8 +321,8 @@ __global__ __launch_bounds__(SPLAT_THREADS) void bev_emit_keys_kernel(DevCfg c, 
     SplatLds& s = *reinterpret_cast<SplatLds*>(smem);
     const int t = blockIdx.x, tx0 = (t % tiles_x) * TILE_W, ty0 = (t / tiles_x) * TILE_H;
     for (int i = threadIdx.x; i < TILE_H * TILE_W; i += SPLAT_THREADS) {
-        const int x = tx0 + i % TILE_W, y = ty0 + i / TILE_W;
-        s.tile[i] = (x < c.W && y < c.H) ? keys[(size_t)y * c.W + x] : 0u;
+        const int lx = i % TILE_W, ly = i / TILE_W, x = tx0 + lx, y = ty0 + ly;
+        s.tile[ly * TILE_LD + lx] = (x < c.W && y < c.H) ? keys[(size_t)y * c.W + x] : 0u;
     }
     __syncthreads();
     emit_tile<true>(c, s, colours, bev, bitmaps, dbg_keys, t, tiles_x * tiles_y, tx0, ty0);
