@@ -271,9 +271,10 @@ def main() -> None:
                        "shape": shape, "hypotheses_per_gpu": args.hyps, "panos": args.panos, "renders_per_hypothesis": S,
                        "cached_identity_renders": args.panos * S, "chunk": args.chunk, "hip_streams": 1 if args.no_overlap else args.streams,
                        "parallelism": f"hypothesis-shard x{world}", "rccl": bool(use_dist)},
-            # the rasteriser as a whole (two scatter passes + densify): SURVEY 8d's bytes per render x the renders of one launch /
-            # the summed average durations of those launches (HIP events on the launching streams)
-            "roofline": {"kernel": "rasteriser: bev_scatter_kernel x2 + bev_densify_kernel", "bound": "hbm",
+            # the rasteriser as a whole (splat + densify): SURVEY 8d's bytes per render x the renders of one launch /
+            # the summed average durations of those launches (HIP events on the launching streams).  The pose-independent
+            # panorama index (bev_pano_index_kernel, once per panorama set at load_panos) is outside the step, like the uploads.
+            "roofline": {"kernel": "rasteriser: bev_splat_kernel + bev_densify_kernel", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": None if ras_traffic is None else int(ras_traffic * renders), "traffic_source": ras_src,
                          "launch_ms": round(ras_ms, 3), "scatter_ms": round(scat_ms, 3), "densify_ms": round(dens_ms, 3),

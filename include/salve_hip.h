@@ -36,7 +36,8 @@ typedef enum {
 
 #define SALVE_HIP_ABI_VERSION 5  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter;
                                      4: salve_bev_tile_pairs; 5: panorama index (salve_bev_pano_index_*), the scatter stage writes the
-                                     sparse image into out_bev (no key image in memory, salve_bev_workspace_init is gone) */
+                                     sparse image into out_bev (no key image in memory, salve_bev_workspace_init is gone), salve_resnet_create
+                                     takes its kernel selection as `flags` -- the library reads no environment variable */
 
 /* Device status word: an optional device int32 the caller zeroes once and passes to the launches below.  Kernels OR bits
  * into it when something went wrong that an int return value cannot report (the launch is asynchronous); the caller
@@ -264,10 +265,25 @@ typedef struct {
     int32_t in2_buf, Cin2, stride2, Hi2, Wi2, reserved2;
 } salve_resnet_op_t;
 
-/* Creates a handle that owns device copies of the (host) weight blobs.  NULL on failure. */
+/* Kernel selection (salve_resnet_create's `flags`; 0 = the product's selection).  Every combination computes the same
+ * network in the same k order with fp32 accumulation and one rounding per stored value: the logits are bit-identical, and
+ * that is what these bits exist for -- the parity tests run a fused / streaming / 8-phase kernel against the plain
+ * implicit-GEMM kernels it replaces.  The library reads NO environment variable (until ABI 4 it did). */
+#define SALVE_RESNET_CONV_IGEMM_ONLY 1   /* conv_igemm_kernel for every convolution (no 8-phase kernel) */
+#define SALVE_RESNET_CONV8_WHEREVER 2    /* the 8-phase 256 x 256 kernel wherever the shape fits, whatever the launch size */
+#define SALVE_RESNET_ROUND_ROBIN_TILES 4 /* natural workgroup order instead of XCD-contiguous tiles */
+#define SALVE_RESNET_NO_STEM_FUSE 8      /* 7x7 convolution and max-pool as two launches */
+#define SALVE_RESNET_NO_BLOCK_FUSE 16    /* the 56 x 56 bottleneck blocks as three convolutions */
+#define SALVE_RESNET_NO_PROJ_FUSE 32     /* ... only the first block of layer 1 (projection shortcut) */
+#define SALVE_RESNET_NO_CHAIN 64         /* no expand_chain_kernel */
+#define SALVE_RESNET_CHAIN_EXPAND_ONLY 128 /* expand_chain_kernel without the next block's first convolution */
+#define SALVE_RESNET_CHAIN_16_WAVES 256  /* its 16-wave / 256-pixel-tile form for the 128-channel shapes */
+#define SALVE_RESNET_CHAIN_NO_SPLIT 512  /* its 8-wave form for the 256-channel shapes too */
+
+/* Creates a handle that owns device copies of the (host) weight blobs.  NULL on failure.  flags: SALVE_RESNET_* (0). */
 void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,
                           const void* weights_f16, size_t weights_bytes, const float* params_f32, size_t params_bytes,
-                          const int32_t* ktab, size_t ktab_entries);
+                          const int32_t* ktab, size_t ktab_entries, int32_t flags);
 void salve_resnet_destroy(void* handle);
 int salve_resnet_num_layers(void* handle);
 /* Device workspace needed for a batch (activation buffers). */

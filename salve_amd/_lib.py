@@ -46,6 +46,9 @@ EXPORTED_SYMBOLS = (
     "salve_resnet_forward",
     "salve_resnet_num_layers",
 )
+# salve_resnet_create flags (include/salve_hip.h: SALVE_RESNET_*): kernel selection for the bit-identity tests; 0 = product
+RESNET_CONV_IGEMM_ONLY, RESNET_CONV8_WHEREVER, RESNET_ROUND_ROBIN_TILES, RESNET_NO_STEM_FUSE, RESNET_NO_BLOCK_FUSE = 1, 2, 4, 8, 16
+RESNET_NO_PROJ_FUSE, RESNET_NO_CHAIN, RESNET_CHAIN_EXPAND_ONLY, RESNET_CHAIN_16_WAVES, RESNET_CHAIN_NO_SPLIT = 32, 64, 128, 256, 512
 STATUS_WALK_FAILED = 1
 STATUS_FP16_RANGE = 2
 STATUS_BAD_HYPOTHESIS = 4
@@ -126,7 +129,7 @@ def load() -> ctypes.CDLL:
     lib.salve_bev_tile_pairs.restype = ctypes.c_int
     lib.salve_resize_rgb_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp]
     lib.salve_resize_rgb_u8.restype = ctypes.c_int
-    lib.salve_resnet_create.argtypes = [i32, i32, vp, i32, vp, sz, vp, sz, vp, sz]
+    lib.salve_resnet_create.argtypes = [i32, i32, vp, i32, vp, sz, vp, sz, vp, sz, i32]
     lib.salve_resnet_create.restype = vp
     lib.salve_resnet_destroy.argtypes = [vp]
     lib.salve_resnet_destroy.restype = None

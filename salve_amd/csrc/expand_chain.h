@@ -43,6 +43,11 @@
 // fit 128 registers per lane and four waves per SIMD issue where two did (the 256-channel shapes are issue-bound, not
 // memory-bound: DESIGN.md section 4.4b).
 
+#ifdef SALVE_BUILD_ABLATIONS
+#define CHAIN_DBG(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define CHAIN_DBG(p, bit) false
+#endif
 struct ChainArgs {
     const uint16_t* t2;    // [M][MID]
     const uint16_t* x;     // [M][4 MID]   residual
@@ -55,7 +60,8 @@ struct ChainArgs {
     const uint16_t* zeros;
     int M, n_tiles;
     int32_t* status;
-    int dbg;   // development (timing only, wrong results): 1 = no weight LDS-DMA after the prologue, 2 = no item LDS-DMA, 4 = no Y stores
+    int dbg;   // ABLATION BUILD ONLY (-DSALVE_BUILD_ABLATIONS; timing only, wrong results): 1 = no weight LDS-DMA after the prologue,
+               // 2 = no item LDS-DMA, 4 = no Y stores.  The product build compiles the tests of these bits out (CHAIN_DBG).
 };
 
 __device__ __forceinline__ int ec_slot(int row, int q) {   // element offset of k-chunk q of row `row` in a [rows][32] image
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
         }
     };
     auto store_prev = [&]() {   // storer waves: the previous RES step's Y chunk, 512 pieces of 16 bytes, 2 per lane (a row's 64 bytes = 4 lanes)
-        if (p.dbg & 4) return;
+        if (CHAIN_DBG(p, 4)) return;
         const uint16_t* Yc = Ring + prev_slot * EC_ITEM_E;
         char* ybase = reinterpret_cast<char*>(p.y) + prev_m0 * (C4 * 2) + prev_nc * 64;   // wave-uniform
         act8 vh[PIECES];
@@ -284,9 +290,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
     };
     // the loader's side of a step: issue for later steps; returns nothing, records whether the stream has ended
     auto loader_issue = [&](bool res_step) {
-        if (p_g < T) { if (!(p.dbg & 2)) issue_item(); else { p_g++; if (++p_s == SPT) { p_s = 0; p_ti++; } if (++p_slot == R) p_slot = 0; } }
+        if (p_g < T) { if (!CHAIN_DBG(p, 2)) issue_item(); else { p_g++; if (++p_s == SPT) { p_s = 0; p_ti++; } if (++p_slot == R) p_slot = 0; } }
         else tail = true;
-        if (res_step && !(p.dbg & 1)) issue_weights();
+        if (res_step && !CHAIN_DBG(p, 1)) issue_weights();
     };
 
     for (int ti = 0; ti < n_my; ti++) {

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
 }
 
 #ifdef SALVE_BUILD_ABLATIONS   // the measured-and-rejected wide-tile kernels d / e / f: tools/build_ablations.sh only
-#include "conv_wide.h"
+#include "../../tools/ablations/conv_wide.h"
 #endif
 #include "conv8.h"
 #include "stem_pool.h"
@@ -857,8 +857,8 @@ struct ResnetHandle {
     std::vector<int> chain;  // per op: 1 = this expand convolution (+ residual) runs as expand_chain_kernel, 2 = ... together with
                              //         the next op, the following block's first 1x1 convolution (expand_chain.h)
     int n_cus = 256;
-    int chain_split = 1;                  // SALVE_CHAIN_SPLIT=0: the 8-wave form for the 256-channel shapes too
-    int chain_dbg = 0, chain_waves = 8;   // development: SALVE_CHAIN_DBG (timing-only ablations of expand_chain_kernel), SALVE_CHAIN_WAVES = 8 | 16
+    int chain_split = 1;                  // SALVE_RESNET_CHAIN_NO_SPLIT: the 8-wave form for the 256-channel shapes too
+    int chain_dbg = 0, chain_waves = 8;   // chain_dbg: ablation build only (timing-only switches of expand_chain_kernel); SALVE_RESNET_CHAIN_16_WAVES
 };
 
 // expand_chain_kernel shapes: (MID, MIDN) of the chained form, MID of the expand-only form
@@ -918,7 +918,7 @@ extern "C" {
 
 void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,
                           const void* weights_f16, size_t weights_bytes, const float* params_f32, size_t params_bytes,
-                          const int32_t* ktab, size_t ktab_entries) {
+                          const int32_t* ktab, size_t ktab_entries, int32_t flags) {
     if (!ops || n_ops <= 0 || !weights_f16 || !params_f32 || !ktab) {
         salve_fail("salve_resnet_create: null argument");
         return nullptr;
@@ -940,25 +940,19 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
     }
     h->wide.assign(h->ops.size(), 0);
     {
-        // unset: the 8-phase kernel on the compute-bound shapes that fit it; 0: conv_igemm_kernel everywhere; 8: the 8-phase
-        // kernel wherever it fits; d, e, f: that alternative kernel of conv_wide.h wherever the shape allows it
-        const char* e = getenv("SALVE_CONV_WIDE");
-#ifdef SALVE_BUILD_ABLATIONS
-        const int mode = !e ? WIDE_AUTO : (e[0] == 'd' ? WIDE_256_K64_S2 : (e[0] == 'e' ? WIDE_128_K64_S1 : (e[0] == 'f' ? WIDE_PC_128 : (e[0] == '8' ? WIDE_8PHASE : WIDE_OFF))));
-#else
-        const int mode = !e ? WIDE_AUTO : (e[0] == '8' ? WIDE_8PHASE : WIDE_OFF);
+        // default: the 8-phase kernel on the compute-bound shapes that fit it, in launches large enough for it
+        int mode = (flags & SALVE_RESNET_CONV_IGEMM_ONLY) ? WIDE_OFF : ((flags & SALVE_RESNET_CONV8_WHEREVER) ? WIDE_8PHASE : WIDE_AUTO);
+#ifdef SALVE_BUILD_ABLATIONS   // development build only: the rejected wide-tile kernels d / e / f of tools/ablations/conv_wide.h
+        if (const char* e = getenv("SALVE_CONV_WIDE")) mode = e[0] == 'd' ? WIDE_256_K64_S2 : (e[0] == 'e' ? WIDE_128_K64_S1 : (e[0] == 'f' ? WIDE_PC_128 : mode));
 #endif
         h->wide_auto = mode == WIDE_AUTO;
         for (size_t i = 0; i < h->ops.size(); i++) h->wide[i] = choose_wide(h->ops[i], mode);
     }
-    {
-        const char* e = getenv("SALVE_XCD_CONTIG");
-        h->xcd_contig = (e && atoi(e) == 0) ? 0 : 1;
-    }
+    h->xcd_contig = (flags & SALVE_RESNET_ROUND_ROBIN_TILES) ? 0 : 1;
     h->stem.assign(h->ops.size(), 0);
     {
-        const char* e = getenv("SALVE_STEM_FUSE");   // "0": keep the implicit-GEMM stem and the separate max-pool
-        for (size_t i = 0; (!e || atoi(e) != 0) && i + 1 < h->ops.size(); i++) {
+        const bool enable = !(flags & SALVE_RESNET_NO_STEM_FUSE);   // else: the implicit-GEMM stem and the separate max-pool
+        for (size_t i = 0; enable && i + 1 < h->ops.size(); i++) {
             const salve_resnet_op_t &a = h->ops[i], &b = h->ops[i + 1];
             if (a.op != SALVE_OP_CONV || b.op != SALVE_OP_MAXPOOL) continue;
             const bool shape = a.KH == 7 && a.KW == 8 && a.stride == 2 && a.pad == 3 && a.Cin == 8 && a.Cout == 64 && a.relu &&
@@ -976,8 +970,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
     }
     h->fused.assign(h->ops.size(), 0);
     {
-        const char* e = getenv("SALVE_RESNET_FUSE");
-        const bool enable = !e || atoi(e) != 0;
+        const bool enable = !(flags & SALVE_RESNET_NO_BLOCK_FUSE);
         for (size_t i = 0; enable && i + 2 < h->ops.size(); i++) {
             const salve_resnet_op_t &a = h->ops[i], &b = h->ops[i + 1], &c = h->ops[i + 2];
             if (a.op != SALVE_OP_CONV || b.op != SALVE_OP_CONV || c.op != SALVE_OP_CONV) continue;
@@ -995,7 +988,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
                               b.in2_buf == SALVE_NO_BUF && b.Cin == mid && b.Cout == mid && b.in_buf == a.out_buf && c.KH == 1 && c.KW == 1 && c.stride == 1 &&
                               c.pad == 0 && c.relu && c.res_buf == SALVE_NO_BUF && c.Cin == mid && c.Cout == 4 * mid && c.in_buf == b.out_buf &&
                               c.in2_buf == a.in_buf && c.Cin2 == mid && c.stride2 == 1 && c.out_buf != a.in_buf && a.in_buf >= 0 && a.Hi == c.Ho &&
-                              a.Wi == c.Wo && b.Hi == a.Hi && b.Ho == a.Hi && c.Hi2 == a.Hi && c.Wi2 == a.Wi && !getenv("SALVE_RESNET_NO_PROJ_FUSE");
+                              a.Wi == c.Wo && b.Hi == a.Hi && b.Ho == a.Hi && c.Hi2 == a.Hi && c.Wi2 == a.Wi && !(flags & SALVE_RESNET_NO_PROJ_FUSE);
             if (!(shapes || proj) || mid != 64 || a.Hi % 8 != 0) continue;
             // the two intermediate tensors are not produced by the fused kernel: nobody may read them afterwards
             bool dead = true;
@@ -1012,10 +1005,9 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
     }
     h->chain.assign(h->ops.size(), 0);
     {
-        // SALVE_RESNET_CHAIN: unset / 2 = expand_chain_kernel wherever the shapes allow, chained with the next block's first
-        // convolution where that one follows directly; 1 = the expand convolution only; 0 = the implicit-GEMM kernels
-        const char* e = getenv("SALVE_RESNET_CHAIN");
-        const int mode = e ? atoi(e) : 2;
+        // 2 (default) = expand_chain_kernel wherever the shapes allow, chained with the next block's first convolution where
+        // that one follows directly; 1 = the expand convolution only; 0 = the implicit-GEMM kernels
+        const int mode = (flags & SALVE_RESNET_NO_CHAIN) ? 0 : ((flags & SALVE_RESNET_CHAIN_EXPAND_ONLY) ? 1 : 2);
         for (size_t i = 0; mode > 0 && i < h->ops.size(); i++) {
             const salve_resnet_op_t& c = h->ops[i];
             if (c.op != SALVE_OP_CONV || h->fused[i] || (i >= 1 && h->fused[i - 1]) || (i >= 2 && h->fused[i - 2]) || h->stem[i]) continue;
@@ -1033,9 +1025,11 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
                 if (next) h->chain[i] = 2;
             }
         }
+        h->chain_waves = (flags & SALVE_RESNET_CHAIN_16_WAVES) ? 16 : 8;
+        h->chain_split = (flags & SALVE_RESNET_CHAIN_NO_SPLIT) ? 0 : 1;
+#ifdef SALVE_BUILD_ABLATIONS   // development build only: timing-only switches of expand_chain_kernel (they compute WRONG results)
         if (const char* d = getenv("SALVE_CHAIN_DBG")) h->chain_dbg = atoi(d);
-        if (const char* d = getenv("SALVE_CHAIN_WAVES")) h->chain_waves = atoi(d);
-        if (const char* d = getenv("SALVE_CHAIN_SPLIT")) h->chain_split = atoi(d);
+#endif
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             h->n_cus = cus;

@@ -54,11 +54,12 @@ class EarlyFusionCEResnet(nn.Module):
     def _state_key(self, device: torch.device):
         return (str(device), tuple((k, v._version, v.data_ptr()) for k, v in self.state_dict().items()))
 
-    def compiled(self, device: torch.device) -> HipResNet:
-        """Fold + pack the current weights for `device` (cached until a parameter changes)."""
-        key = self._state_key(device)
+    def compiled(self, device: torch.device, flags: int = 0) -> HipResNet:
+        """Fold + pack the current weights for `device` (cached until a parameter changes).  flags: the library's kernel
+        selection (_lib.RESNET_*; 0 = the product's -- development tools and the bit-identity tests pass others)."""
+        key = (self._state_key(device), int(flags))
         if self._compiled is None or self._compiled_key != key:
-            self._compiled = HipResNet(self.state_dict(), self.num_layers, device)
+            self._compiled = HipResNet(self.state_dict(), self.num_layers, device, flags=flags)
             self._compiled_key = key
         return self._compiled
 

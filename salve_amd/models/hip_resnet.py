@@ -173,7 +173,8 @@ def build_program(state_dict: Dict[str, torch.Tensor], num_layers: int, in_hw: T
 class HipResNet:
     """A compiled verifier on one GPU: immutable device weights inside a library handle + a workspace."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], num_layers: int, device: torch.device) -> None:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_layers: int, device: torch.device, flags: int = 0) -> None:
+        """flags: _lib.RESNET_* kernel selection (0 = the product's; the bit-identity tests pass the others)."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -186,7 +187,7 @@ class HipResNet:
             h = self.lib.salve_resnet_create(
                 num_layers, cin_p, ops.ctypes.data_as(ctypes.c_void_p), len(ops),
                 wbits.ctypes.data_as(ctypes.c_void_p), wbits.nbytes, params.ctypes.data_as(ctypes.c_void_p), params.nbytes,
-                ktab.ctypes.data_as(ctypes.c_void_p), ktab.size,
+                ktab.ctypes.data_as(ctypes.c_void_p), ktab.size, int(flags),
             )
         if not h:
             _lib.check(-1, "salve_resnet_create")

@@ -43,9 +43,9 @@ def _handles(lib, monkeypatch, shape, seed, mode8):
     kt = np.concatenate(bld.ktab).astype(np.int32)
     out = []
     for mode in ("0", mode8):
-        monkeypatch.setenv("SALVE_CONV_WIDE", mode)   # read when the handle is created
+        flags = _lib.RESNET_CONV8_WHEREVER if mode == "8" else _lib.RESNET_CONV_IGEMM_ONLY
         h = lib.salve_resnet_create(0, cin, ops.ctypes.data_as(ctypes.c_void_p), 1, wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
-                                    pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size)
+                                    pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, flags)
         assert h, lib.salve_last_error()
         out.append(ctypes.c_void_p(h))
     return out

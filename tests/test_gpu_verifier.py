@@ -31,7 +31,7 @@ def run_single_conv(w, b, x_nhwc, stride, pad, relu, res=None, kw_pad=0):
         ops[1]["out_buf"] = 1
         ops = ops[:1] if False else ops
     h = lib.salve_resnet_create(0, Cp, ops.ctypes.data_as(ctypes.c_void_p), len(ops), wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
-                                pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size)
+                                pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, 0)
     assert h
     h = ctypes.c_void_p(h)
     need = lib.salve_resnet_workspace_bytes(h, B)
@@ -45,7 +45,7 @@ def run_single_conv(w, b, x_nhwc, stride, pad, relu, res=None, kw_pad=0):
         ops1 = ops[:1]
         lib.salve_resnet_destroy(h)
         h = ctypes.c_void_p(lib.salve_resnet_create(0, Cp, ops.ctypes.data_as(ctypes.c_void_p), 1, wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
-                                                     pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
+                                                     pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, 0))
         # one op, but the workspace keeps room for two buffers (the residual lives in buffer 1)
     logits = torch.zeros((B, 2), dtype=torch.float32, device=DEV)
     xd = x_nhwc.to(DEV).contiguous()
@@ -100,6 +100,7 @@ def tile_like_inputs(n, batch, seed=0):
     (50, ["floor_rgb_texture"], 5),
     (152, ["ceiling_rgb_texture", "floor_rgb_texture"], 2),
     (18, ["layout"], 3),
+    (50, ["ceiling_rgb_texture", "floor_rgb_texture", "layout"], 3),   # six images, 18 channels through the stem (early_fusion.py:30-32, 59-60)
 ])
 def test_logits_match_oracle(num_layers, modalities, batch):
     """north_star: classifier logits within 1e-3 of the reference's.  The oracle runs in fp32 on the SAME fp32 tiles the
@@ -181,7 +182,7 @@ def test_conv_with_projection_shortcut_as_second_source(stride, hw, cx, mid, cou
     ops = np.array(bld.ops, dtype=hip_resnet.OP_DTYPE)
     wts, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
     h = ctypes.c_void_p(lib.salve_resnet_create(0, cx, ops.ctypes.data_as(ctypes.c_void_p), len(ops), wts.ctypes.data_as(ctypes.c_void_p), wts.nbytes,
-                                                 pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
+                                                 pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, 0))
     assert h
     need = lib.salve_resnet_workspace_bytes(h, B)
     ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
@@ -203,11 +204,11 @@ def test_conv_with_projection_shortcut_as_second_source(stride, hw, cx, mid, cou
 
 
 @pytest.mark.parametrize("K,Cout", [(64, 64), (1024, 256)])   # conv_igemm_kernel; conv8_kernel (forced)
-def test_convolution_without_relu_saturates_and_reports_both_signs(K, Cout, monkeypatch):
+def test_convolution_without_relu_saturates_and_reports_both_signs(K, Cout):
     """The general convolution kernels take their ReLU as a launch argument: without it the stored value saturates at
     +-65504 and EITHER side raises SALVE_STATUS_FP16_RANGE (the low side is tracked as a minimum of its own, resnet.hip:
     pack4_lo); with it a hugely negative sum stores 0 and raises nothing."""
-    monkeypatch.setenv("SALVE_CONV_WIDE", "8" if K >= 512 else "0")
+    flags = _lib.RESNET_CONV8_WHEREVER if K >= 512 else _lib.RESNET_CONV_IGEMM_ONLY
     lib = _lib.load()
     B, hw = 2, 32
     x = torch.ones(B, hw, hw, K, dtype=torch.float16)
@@ -219,7 +220,7 @@ def test_convolution_without_relu_saturates_and_reports_both_signs(K, Cout, monk
         ops = np.array(bld.ops, dtype=hip_resnet.OP_DTYPE)
         wts, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
         h = ctypes.c_void_p(lib.salve_resnet_create(0, K, ops.ctypes.data_as(ctypes.c_void_p), len(ops), wts.ctypes.data_as(ctypes.c_void_p), wts.nbytes,
-                                                     pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
+                                                     pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, flags))
         assert h
         need = lib.salve_resnet_workspace_bytes(h, B)
         ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
@@ -237,7 +238,7 @@ def test_convolution_without_relu_saturates_and_reports_both_signs(K, Cout, monk
         assert bool(int(word.item()) & _lib.STATUS_FP16_RANGE) == expect_flag, (sign, relu, int(word.item()))
 
 
-def test_fused_bottleneck_is_bit_identical_to_three_kernels(monkeypatch):
+def test_fused_bottleneck_is_bit_identical_to_three_kernels():
     """The fused bottleneck kernel (resnet.hip: bottleneck_kernel) keeps t1 / t2 in LDS but rounds them to fp16 and
     accumulates in the same k order as the three separate convolutions: the logits must agree bit for bit."""
     torch.manual_seed(5)
@@ -247,21 +248,20 @@ def test_fused_bottleneck_is_bit_identical_to_three_kernels(monkeypatch):
     x = torch.randn(3, 224, 224, 8).to(torch.float16).to(DEV)
     x[..., 6:] = 0
     outs = []
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("SALVE_RESNET_FUSE", fuse)   # read when the handle is created
-        eng = hip_resnet.HipResNet(model.state_dict(), 50, torch.device(DEV))
+    for flags in (0, _lib.RESNET_NO_BLOCK_FUSE, _lib.RESNET_NO_PROJ_FUSE):
+        eng = hip_resnet.HipResNet(model.state_dict(), 50, torch.device(DEV), flags=flags)
         outs.append(eng.forward_nhwc(x).clone())
         torch.cuda.synchronize()
     assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("layers,batch", [(50, 3), (50, 37), (152, 2)])
-def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(monkeypatch, layers, batch):
+def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(layers, batch):
     """expand_chain_kernel (csrc/expand_chain.h) runs a block's last 1x1 convolution + residual and, chained, the next block's
     first 1x1 convolution as one persistent streaming kernel with LDS-DMA rings and counted waits.  Same k order, fp32
     accumulation and single rounding of Y as the implicit-GEMM kernels: the logits must agree bit for bit with
-    SALVE_RESNET_CHAIN=0, for the expand-only form (1) and the chained form (2, the default).  Batches whose pixel counts are
+    SALVE_RESNET_NO_CHAIN ("0"), for the expand-only form ("1") and the chained form ("2", the default).  Batches whose pixel counts are
     not multiples of the 128-pixel tile (3 x 784, 37 x 196, ...) exercise the rows beyond M; 37 x 784 pixels give every one
     of the 256 persistent workgroups several tiles, the last round only some."""
     torch.manual_seed(9)
@@ -274,10 +274,10 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(monke
     x[..., (6 if layers == 50 else 12):] = 0
     outs = {}
     for mode in ("0", "1", "2", "2w", "2n", "1n"):
-        monkeypatch.setenv("SALVE_RESNET_CHAIN", mode[0])   # read when the handle is created
-        monkeypatch.setenv("SALVE_CHAIN_WAVES", "16" if mode.endswith("w") else "8")   # "2w": the 16-wave / 256-pixel-tile variant
-        monkeypatch.setenv("SALVE_CHAIN_SPLIT", "0" if mode.endswith("n") else "1")    # "n": no channel split (8 waves) for the 256-channel shapes
-        eng = hip_resnet.HipResNet(model.state_dict(), layers, torch.device(DEV))
+        flags = {"0": _lib.RESNET_NO_CHAIN, "1": _lib.RESNET_CHAIN_EXPAND_ONLY, "2": 0}[mode[0]]
+        flags |= _lib.RESNET_CHAIN_16_WAVES if mode.endswith("w") else 0    # "2w": the 16-wave / 256-pixel-tile variant
+        flags |= _lib.RESNET_CHAIN_NO_SPLIT if mode.endswith("n") else 0    # "n": no channel split (8 waves) for the 256-channel shapes
+        eng = hip_resnet.HipResNet(model.state_dict(), layers, torch.device(DEV), flags=flags)
         for rep in range(3):                             # a misplaced wait in a ring shows up as a rare wrong tile: repeat
             o = eng.forward_nhwc(x).clone()
             torch.cuda.synchronize()
@@ -292,7 +292,7 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(monke
     assert torch.equal(outs["2n"], outs["0"]) and torch.equal(outs["1n"], outs["0"]), "8-wave form of the 256-channel shapes differs"
 
 
-def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool(monkeypatch):
+def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool():
     """stem_pool_kernel (7x7 / 2 convolution + BatchNorm + ReLU + 3x3 / 2 max-pool in one launch, input patch in LDS) rounds
     every convolution output to fp16 before the max, exactly as the two-kernel path stores it, and accumulates in the same k
     order: the logits must agree bit for bit -- image borders (zero padding, pooling windows cut by the edge) included."""
@@ -303,20 +303,19 @@ def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool(monkeypatch):
     x = torch.randn(3, 224, 224, 8).to(torch.float16).to(DEV)
     x[..., 6:] = 0
     outs = []
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("SALVE_STEM_FUSE", fuse)   # read when the handle is created
-        eng = hip_resnet.HipResNet(model.state_dict(), 18, torch.device(DEV))
+    for flags in (0, _lib.RESNET_NO_STEM_FUSE):
+        eng = hip_resnet.HipResNet(model.state_dict(), 18, torch.device(DEV), flags=flags)
         outs.append(eng.forward_nhwc(x).clone())
         torch.cuda.synchronize()
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("cfg", ["0", "8"])
-def test_alternative_convolution_kernels_are_bit_identical(monkeypatch, cfg):
-    """SALVE_CONV_WIDE = 0 | 8 routes the convolutions through conv_igemm_kernel everywhere / the 8-phase 256 x 256 kernel
-    wherever it fits (read when the handle is created; the rejected wide-tile kernels d / e / f exist in the ablation build
-    only).  Same k order and fp32 accumulation: the logits of ResNet-50 must agree bit for bit with the default selection."""
+@pytest.mark.parametrize("cfg", [_lib.RESNET_CONV_IGEMM_ONLY, _lib.RESNET_CONV8_WHEREVER, _lib.RESNET_ROUND_ROBIN_TILES], ids=["igemm", "conv8", "round-robin"])
+def test_alternative_convolution_kernels_are_bit_identical(cfg):
+    """SALVE_RESNET_CONV_IGEMM_ONLY / SALVE_RESNET_CONV8_WHEREVER route the convolutions through conv_igemm_kernel everywhere / the
+    8-phase 256 x 256 kernel wherever it fits (flags of salve_resnet_create; the rejected wide-tile kernels d / e / f exist in the
+    ablation build only); SALVE_RESNET_ROUND_ROBIN_TILES changes the workgroup -> tile order.  Same k order and fp32 accumulation: the logits of ResNet-50 must agree bit for bit with the default selection."""
     torch.manual_seed(6)
     model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"]))
     randomise_bn(model, seed=6)
@@ -324,12 +323,8 @@ def test_alternative_convolution_kernels_are_bit_identical(monkeypatch, cfg):
     x = torch.randn(5, 224, 224, 8).to(torch.float16).to(DEV)
     x[..., 6:] = 0
     outs = []
-    for v in (None, cfg):
-        if v is None:
-            monkeypatch.delenv("SALVE_CONV_WIDE", raising=False)
-        else:
-            monkeypatch.setenv("SALVE_CONV_WIDE", v)
-        eng = hip_resnet.HipResNet(model.state_dict(), 50, torch.device(DEV))
+    for v in (0, cfg):
+        eng = hip_resnet.HipResNet(model.state_dict(), 50, torch.device(DEV), flags=v)
         outs.append(eng.forward_nhwc(x).clone())
         torch.cuda.synchronize()
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])

@@ -37,6 +37,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.salve_last_error() is not None
 
 
+def test_product_library_reads_no_environment_variable():
+    """Kernel selection is an argument (salve_resnet_create flags, ABI 5), never the environment: a stray variable in a user's
+    shell must not change which kernels a production run uses.  The built library does not even import getenv."""
+    import subprocess
+
+    _lib.load()
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", str(_lib.LIB_PATH)], check=True, capture_output=True, text=True).stdout
+    assert "getenv" not in undefined
+    for src in sorted((ROOT / "salve_amd" / "csrc").glob("*")):
+        text = src.read_text()
+        for i, line in enumerate(text.splitlines()):
+            if "getenv(" in line:   # only inside the ablation build's #ifdef blocks
+                before = text.splitlines()[max(0, i - 3):i + 1]
+                assert any("SALVE_BUILD_ABLATIONS" in b for b in before), f"{src.name}:{i + 1}: {line.strip()}"
+
+
 def test_product_has_no_cpu_path():
     from salve_amd.rasteriser import BevRasteriser
 

@@ -9,7 +9,7 @@ from salve_amd.models.early_fusion import EarlyFusionCEResnet
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
-eng = model.compiled(dev)
+eng = model.compiled(dev, flags=int(os.environ.get("SALVE_RESNET_FLAGS", "0")))
 B = 4096
 x = torch.randn(B, 224, 224, eng.in_channels, device=dev).to(torch.float16)
 for _ in range(2):

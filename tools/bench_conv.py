@@ -1,3 +1,4 @@
+import os
 """Single-convolution timings of the verifier's shapes, one configuration of the convolution kernels per run (GPU box).
 usage: SALVE_CONV_WIDE=0|a|b|c|d python tools/bench_conv.py [batch]     prints one line per ResNet-50 shape:
 time, TFLOP/s, and the checksum / max-abs of the output (to compare configurations with each other)."""
@@ -50,7 +51,7 @@ for name, cin, cout, k, stride, pad, hw, res, src2 in SHAPES:
     ops = np.array(bld.ops, dtype=hip_resnet.OP_DTYPE)
     wb, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
     mk = lambda o, n: ctypes.c_void_p(lib.salve_resnet_create(0, cin, o.ctypes.data_as(ctypes.c_void_p), n, wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
-                                                              pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
+                                                              pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, int(os.environ.get("SALVE_RESNET_FLAGS", "0"))))
     # the handle sizes ONE activation buffer (the output); buffer 1 (residual / second source) lies behind it in the workspace
     out_elems = ho * ho * cout
     other = out_elems if src2 is None else max(out_elems, src2[2] * src2[2] * src2[0])

@@ -1,3 +1,4 @@
+import os
 """Experiment (GPU box): two verifier forwards on two HIP streams, the second one started half a forward later, so that the
 HBM-bound layers of one overlap the MFMA-bound layers of the other.  Compared with the same work on one stream."""
 import sys, time
@@ -10,7 +11,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
-e1, e2 = model.compiled(dev), model.compiled(dev)
+e1, e2 = model.compiled(dev, flags=int(os.environ.get("SALVE_RESNET_FLAGS", "0"))), model.compiled(dev, flags=int(os.environ.get("SALVE_RESNET_FLAGS", "0")))
 x1 = torch.randn(B, 224, 224, e1.in_channels, device=dev).to(torch.float16)
 x2 = torch.randn(B, 224, 224, e1.in_channels, device=dev).to(torch.float16)
 s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)

@@ -1,3 +1,4 @@
+import os
 """Stem (7x7/2 convolution + max-pool) alone at batch B (GPU box).  SALVE_STEM_FUSE=0|1, SALVE_HIP_LIB for ablation builds."""
 import ctypes, os, sys
 from pathlib import Path
@@ -17,7 +18,7 @@ bld.maxpool(0, 1, H, W, 64)
 ops = np.array(bld.ops, dtype=hip_resnet.OP_DTYPE)
 wb, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
 h = ctypes.c_void_p(lib.salve_resnet_create(0, 8, ops.ctypes.data_as(ctypes.c_void_p), 2, wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
-                                             pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
+                                             pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, int(os.environ.get("SALVE_RESNET_FLAGS", "0"))))
 need = lib.salve_resnet_workspace_bytes(h, B)
 ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
 x = (torch.randn(B, 224, 224, 8, generator=g) * 0.5).to(torch.float16).to(DEV)

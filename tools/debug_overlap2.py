@@ -93,7 +93,7 @@ if mode.startswith("op_"):
     ops = np.array(bld.ops, dtype=hr.OP_DTYPE)
     wb, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
     h = ctypes.c_void_p(lib.salve_resnet_create(0, cin, ops.ctypes.data_as(ctypes.c_void_p), len(ops), wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
-                                                pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size))
+                                                pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, 0))
     ws = torch.zeros(lib.salve_resnet_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
     xin = torch.randn(B, hw, hw, cin, device=dev).to(torch.float16)
     logits = torch.zeros(B, 2, device=dev)

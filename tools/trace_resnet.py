@@ -1,3 +1,4 @@
+import os
 """One ResNet-50 forward after warm-up (GPU box; run under rocprofv3 --kernel-trace / --pmc to get per-launch numbers).
 usage: trace_resnet.py [batch] [ops.json]   -- ops.json receives the op program (shapes) the launches execute."""
 import json, sys
@@ -12,7 +13,7 @@ torch.manual_seed(0)
 layers = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 mods = ["floor_rgb_texture"] if layers != 152 else ["ceiling_rgb_texture", "floor_rgb_texture"]
 model = EarlyFusionCEResnet(layers, False, 2, SimpleNamespace(modalities=mods)).eval()
-eng = model.compiled(dev)
+eng = model.compiled(dev, flags=int(os.environ.get("SALVE_RESNET_FLAGS", "0")))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 if len(sys.argv) > 2:
     ops = hip_resnet.build_program(model.state_dict(), layers)[0]
