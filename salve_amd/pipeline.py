@@ -114,20 +114,30 @@ class RenderVerifyPipeline:
 
     # ------------------------------------------------------------------ hypotheses
     def prepare(self, hyp: HypothesisTable):
-        """Upload the render table and the tile job tables of a hypothesis shard (once, outside the timed loop)."""
+        """Upload the render table and the tile job tables of a hypothesis shard (once, outside the timed loop).
+
+        Inside every chunk the renders are issued in the order of their panorama (a stable sort by i1): the workgroups of
+        consecutive renders run side by side, and those of one panorama then read its depth blocks, box table and colours
+        through the L2s while they are warm (the splat kernel: -10 % at 64 panoramas).  Nothing else changes: the tile jobs
+        name each hypothesis's render by its rank, so tiles, logits and in-window counts stay in hypothesis order."""
         N, S = len(hyp), len(self.surfaces)
         surf_ids = [SURFACES[s] for s in self.surfaces]
-        rows = pack_hypotheses(np.repeat(hyp.i1, S), np.tile(surf_ids, N), np.repeat(hyp.R, S, axis=0), np.repeat(hyp.t, S, axis=0),
-                               np.ones(N * S))
+        i1 = np.asarray(hyp.i1).astype(np.int64)
+        order = np.concatenate([lo + np.argsort(i1[lo:lo + self.chunk], kind="stable") for lo in range(0, N, self.chunk)]) if N else np.zeros(0, np.int64)
+        rank = np.empty(N, dtype=np.int64)          # rank[j]: position of hypothesis j in the render order of the whole table
+        rank[order] = np.arange(N)
+        rows = pack_hypotheses(np.repeat(i1[order], S), np.tile(surf_ids, N), np.repeat(np.asarray(hyp.R)[order], S, axis=0),
+                               np.repeat(np.asarray(hyp.t)[order], S, axis=0), np.ones(N * S))
         j = np.arange(N)
         slot = j % self.chunk
+        rslot = rank % self.chunk                   # the hypothesis's render inside its chunk's image buffer
         # tile order inside a surface's channel pair: (posed i1, identity i2) unless the file names of the pair sort the
         # other way round (zind_data.py:110)
         swap = np.zeros(N, dtype=np.int64) if hyp.swap is None else np.asarray(hyp.swap).astype(np.int64)
         jobs1_bev, jobs1_slot, jobs1_chan = [], [], []
         jobs2_bev, jobs2_slot, jobs2_chan = [], [], []
         for si in range(S):
-            jobs1_bev.append(slot * S + si)           # render output of this chunk
+            jobs1_bev.append(rslot * S + si)          # render output of this chunk
             jobs1_slot.append(slot)
             jobs1_chan.append(6 * si + 3 * swap)
             jobs2_bev.append(hyp.i2.astype(np.int64) * S + si)  # cached identity render of pano i2
@@ -138,14 +148,20 @@ class RenderVerifyPipeline:
         prepared = {
             "n": N,
             "i2": np.asarray(hyp.i2).astype(np.int64),
+            "rank": rank,
             "rows": self.ras.upload_hypotheses(rows),
             "jobs1": self.ras.upload_tile_jobs(st(jobs1_bev), st(jobs1_slot), st(jobs1_chan)),
             "jobs2": self.ras.upload_tile_jobs(st(jobs2_bev), st(jobs2_slot), st(jobs2_chan)),
-            "in_window": torch.zeros(N * S, dtype=torch.int32, device=self.device),  # posed renders, filled by score()
+            "in_window": torch.zeros(N * S, dtype=torch.int32, device=self.device),  # posed renders IN RENDER ORDER, filled by score()
             "ready": torch.cuda.Event(),   # the tables are on the device: launches on other streams wait for it
         }
         prepared["ready"].record(torch.cuda.current_stream(self.device))
         return prepared
+
+    def bev_index(self, prepared, j: int) -> Tuple[int, int]:
+        """(chunk, first image inside that chunk's BEV buffer) of hypothesis j's posed renders (S consecutive images)."""
+        r = int(prepared["rank"][j])
+        return r // self.chunk, (r % self.chunk) * len(self.surfaces)
 
     @staticmethod
     def _timed(timers, units: int, tag: str):
@@ -252,7 +268,7 @@ class RenderVerifyPipeline:
         at least one point inside the BEV window (bev_rendering_utils.py:279-280, 464-466, 623-627).  Call after score();
         synchronises."""
         S = len(self.surfaces)
-        posed = prepared["in_window"].view(-1, S).cpu().numpy() > 0
+        posed = prepared["in_window"].view(-1, S).cpu().numpy()[prepared["rank"]] > 0
         ident = self.ref_in_window.view(-1, S).cpu().numpy()[prepared["i2"]] > 0
         return (posed & ident).all(axis=1)
 

@@ -125,9 +125,11 @@ def test_full_size_properties():
     pipe3 = RenderVerifyPipeline(model, dev, chunk=40, streams=2)  # two streams: rasteriser | verifier
     pipe3.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     assert torch.equal(a, pipe3.score(pipe3.prepare(table)))
-    pipe.score(pipe.prepare(table.shard(0, 6)))  # the first 16 hypotheses: one chunk, lands in bev[0:16]
+    prep0 = pipe.prepare(table.shard(0, 6))      # the first 16 hypotheses: one chunk
+    pipe.score(prep0)
     torch.cuda.synchronize()
-    assert torch.equal(pipe.bevs[pipe.last_chunk_buffer[0]][0], pipe.ref_bev[int(table.i1[0])])
+    ck, k0 = pipe.bev_index(prep0, 0)            # where hypothesis 0's render landed (renders run in panorama order)
+    assert torch.equal(pipe.bevs[pipe.last_chunk_buffer[ck]][k0], pipe.ref_bev[int(table.i1[0])])
     # two ranks' shards reproduce the single-rank logits
     parts = [pipe.score(pipe.prepare(table.shard(r, 2))).clone() for r in range(2)]
     assert torch.equal(torch.cat(parts), a)

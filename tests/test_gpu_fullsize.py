@@ -59,11 +59,11 @@ def test_config2_config3_at_benchmark_size():
             # the BEV images still resident after the pass: those of the last chunk (one buffer set) or the last two
             last = sorted(pipe.last_chunk_buffer)[-pipe.nbuf:]
             bev_last = {ci: pipe.bevs[pipe.last_chunk_buffer[ci]].clone() for ci in last}
-            results[streams] = (logits.clone(), bev_last, pipe)
+            results[streams] = (logits.clone(), bev_last, pipe, prepared)
         oracle = pending.get(timeout=900)
 
-    l3, b3, pipe3 = results[3]
-    l1, b1, _ = results[1]
+    l3, b3, pipe3, prep3 = results[3]
+    l1, b1, _, _ = results[1]
     assert torch.isfinite(l3).all()
     assert torch.equal(l3, l1), "logits differ between the three-stream and the one-stream schedule"
     assert torch.equal(b3[3], b1[3]), "BEV images of the last chunk differ between the schedules"
@@ -71,7 +71,8 @@ def test_config2_config3_at_benchmark_size():
     # bit-exact against the oracle, from the overlapped run's own buffers
     ras = pipe3.ras
     for j, (bev_exp, xy_exp) in zip(picked, oracle):
-        chunk, slot = divmod(int(j), CHUNK)
+        chunk, slot = pipe3.bev_index(prep3, int(j))   # (renders are issued in panorama order inside a chunk: pipeline.prepare)
+        assert chunk == int(j) // CHUNK
         got = ras.export_u8(b3[chunk][slot:slot + 1]).cpu().numpy()[0]
         assert bev_exp is not None
         assert np.array_equal(got, bev_exp), f"hypothesis {j}: BEV image differs from the oracle"
@@ -130,7 +131,8 @@ def test_benchmark_launch_shape_against_the_oracle():
         torch.cuda.synchronize()
         pipe.check("benchmark launch shape")
         assert pipe.valid_mask(prepared).all() and torch.isfinite(logits).all()
-        got_bev = pipe.ras.export_u8(pipe.bevs[0][torch.from_numpy(np.sort(picked)).to(dev)]).cpu().numpy()
+        where = np.array([pipe.bev_index(prepared, int(j))[1] for j in np.sort(picked)])   # render order != hypothesis order (pipeline.prepare)
+        got_bev = pipe.ras.export_u8(pipe.bevs[0][torch.from_numpy(where).to(dev)]).cpu().numpy()
         got_logits = logits.cpu().numpy()
         oracle = pending.get(timeout=1200)
     order = {int(j): k for k, j in enumerate(np.sort(picked))}

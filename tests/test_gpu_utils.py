@@ -95,9 +95,11 @@ def test_config5_large_panos_two_surfaces_resnet152():
     pipe = RenderVerifyPipeline(model, dev, pano_hw=(H, W), chunk=4)
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     hyp = synthetic.make_hypotheses(3, 2, seed=2)
-    logits = pipe.score(pipe.prepare(hyp)).cpu()
+    prepared = pipe.prepare(hyp)
+    logits = pipe.score(prepared).cpu()
     torch.cuda.synchronize()
-    bev = pipe.ras.export_u8(pipe.bev[:2]).cpu().numpy()  # hypothesis 0: ceiling, floor of pano i1
+    ck, k0 = pipe.bev_index(prepared, 0)
+    bev = pipe.ras.export_u8(pipe.bevs[pipe.last_chunk_buffer[ck]][k0:k0 + 2]).cpu().numpy()  # hypothesis 0: ceiling, floor of pano i1
     tiles = []
     for si, surface in enumerate(("ceiling", "floor")):
         i1, i2 = int(hyp.i1[0]), int(hyp.i2[0])
