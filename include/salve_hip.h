@@ -207,6 +207,7 @@ int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t b
  *   lut         device float [3, 256]: (v - mean_c) / std_c evaluated in float32 on the host
  *   out         SALVE_TILE_F32_NCHW : float [slots, out_c, crop, crop]
  *               SALVE_TILE_F16_NHWC:  fp16  [slots, crop, crop, out_c]
+ *               SALVE_TILE_U8X4:      uint32 [slots, crop, crop]
  */
 typedef struct {
     int64_t bev_offset; /* element offset of the source image inside `bev` (uint32 units) */
@@ -216,6 +217,9 @@ typedef struct {
 
 #define SALVE_TILE_F32_NCHW 0
 #define SALVE_TILE_F16_NHWC 1
+#define SALVE_TILE_U8X4 2 /* uint32 [slots, crop, crop], 0x00BBGGRR: the Resize + Crop result itself, before ToTensor / Normalize (one
+                             image per slot; chan, out_c and lut's values are not used).  For images that many hypotheses share -- the
+                             identity render of a pair's second panorama -- so that salve_bev_tile_pairs need not resize them again. */
 
 int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs, int32_t n_jobs,
                     const int32_t* coef_y, const int32_t* coef_x, int32_t resize, int32_t crop, const float* lut,
@@ -228,11 +232,14 @@ int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const sal
  * surface, salve/models/early_fusion.py:52-60 -- either order: salve/dataset/zind_data.py:110).  A thread computes both
  * pixels and writes the six channels (and, for the last group of a sample whose out_c leaves padding channels, the zero
  * padding too) with whole-pixel stores, where two salve_bev_tiles calls write three 2-byte channels each.  Same arithmetic
- * as salve_bev_tiles: bit-identical tiles.  (int return: SALVE_ERR_BAD_ARG on null pointers / bad sizes; the pairing rule
- * is the caller's to keep.) */
+ * as salve_bev_tiles: bit-identical tiles.  b_pretiled = 1: bev_b holds SALVE_TILE_U8X4 images (uint32 [*, crop, crop]) and
+ * jobs_b[k].bev_offset is an element offset into THAT array: the second image of a pair is the identity render of a panorama
+ * (bev_rendering_utils.py:455), the same for every hypothesis that names it -- resized and cropped once, only ToTensor +
+ * Normalize per pair (the same integer taps, the same table: bit-identical again).  (int return: SALVE_ERR_BAD_ARG on null
+ * pointers / bad sizes; the pairing rule is the caller's to keep.) */
 int salve_bev_tile_pairs(const uint32_t* bev_a, const uint32_t* bev_b, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs_a,
                          const salve_tile_job_t* jobs_b, int32_t n_pairs, const int32_t* coef_y, const int32_t* coef_x, int32_t resize,
-                         int32_t crop, const float* lut, void* out, int32_t out_c, void* stream);
+                         int32_t crop, const float* lut, void* out, int32_t out_c, int32_t b_pretiled, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Verifier: early-fusion ResNet forward pass (fp16 MFMA, fp32 accumulation).

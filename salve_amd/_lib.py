@@ -20,6 +20,7 @@ SALVE_OK = 0
 EXPECTED_ABI = 5          # include/salve_hip.h: SALVE_HIP_ABI_VERSION
 TILE_F32_NCHW = 0
 TILE_F16_NHWC = 1
+TILE_U8X4 = 2
 
 # every symbol include/salve_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
@@ -125,7 +126,7 @@ def load() -> ctypes.CDLL:
     lib.salve_bev_export_u8.restype = ctypes.c_int
     lib.salve_bev_tiles.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
     lib.salve_bev_tiles.restype = ctypes.c_int
-    lib.salve_bev_tile_pairs.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp]
+    lib.salve_bev_tile_pairs.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
     lib.salve_bev_tile_pairs.restype = ctypes.c_int
     lib.salve_resize_rgb_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp]
     lib.salve_resize_rgb_u8.restype = ctypes.c_int

@@ -697,6 +697,7 @@ __global__ __launch_bounds__(256) void bev_tile_kernel(const uint32_t* __restric
     const uint32_t p00 = img[(size_t)cy.x * W + cx.x], p01 = img[(size_t)cy.x * W + cx.y];
     const uint32_t p10 = img[(size_t)cy.y * W + cx.x], p11 = img[(size_t)cy.y * W + cx.y];
     float v[3];
+    int rq[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         const int a = (p00 >> (8 * ch)) & 255, b = (p01 >> (8 * ch)) & 255;
@@ -705,9 +706,12 @@ __global__ __launch_bounds__(256) void bev_tile_kernel(const uint32_t* __restric
         const int S1 = cc * cx.z + d * cx.w;
         int r = (((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2;
         r = min(max(r, 0), 255);
+        rq[ch] = r;
         v[ch] = lut[ch * 256 + r];
     }
-    if (fmt == SALVE_TILE_F32_NCHW) {
+    if (fmt == SALVE_TILE_U8X4) {   // the resized + cropped image itself (before ToTensor / Normalize): 0x00BBGGRR, one image per slot
+        reinterpret_cast<uint32_t*>(out)[(size_t)job.slot * crop * crop + idx] = (uint32_t)rq[0] | ((uint32_t)rq[1] << 8) | ((uint32_t)rq[2] << 16);
+    } else if (fmt == SALVE_TILE_F32_NCHW) {
         float* o = reinterpret_cast<float*>(out) + ((size_t)job.slot * out_c + job.chan) * crop * crop + idx;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) o[(size_t)ch * crop * crop] = v[ch];
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(256) void bev_tile_pair_kernel(const uint32_t* __re
                                                             const salve_tile_job_t* __restrict__ jobs_a, const salve_tile_job_t* __restrict__ jobs_b,
                                                             const int32_t* __restrict__ coef_y, const int32_t* __restrict__ coef_x, int resize,
                                                             int crop, const float* __restrict__ lut, uint16_t* __restrict__ out, int out_c,
-                                                            int n_pairs, int n_blocks, int xcd_group) {
+                                                            int n_pairs, int n_blocks, int xcd_group, int b_pretiled) {
     // (the workgroups of one pair read the same two BEV images: same id % 8 = same XCD = one L2 -- as in bev_scatter_kernel)
     int job, blk;
     if (xcd_group) {
@@ -761,7 +765,13 @@ __global__ __launch_bounds__(256) void bev_tile_pair_kernel(const uint32_t* __re
     const int4 cx = reinterpret_cast<const int4*>(coef_x)[j + off];
     float va[3], vb[3];
     tile_pixel(bev_a + ja.bev_offset, W, cy, cx, lut, va);
-    tile_pixel(bev_b + jb.bev_offset, W, cy, cx, lut, vb);
+    if (b_pretiled) {   // image b was resized and cropped before (SALVE_TILE_U8X4, once per panorama): ToTensor + Normalize only
+        const uint32_t q = bev_b[jb.bev_offset + idx];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) vb[ch] = lut[ch * 256 + ((q >> (8 * ch)) & 255u)];
+    } else {
+        tile_pixel(bev_b + jb.bev_offset, W, cy, cx, lut, vb);
+    }
     const bool a_first = ja.chan < jb.chan;
     const int c0 = a_first ? ja.chan : jb.chan;   // first of the group's six channels (a multiple of 6)
     uint32_t w[3];                                // the six halves, two per word
@@ -1215,7 +1225,7 @@ int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const sal
         return SALVE_ERR_BAD_ARG;
     }
     if (crop <= 0 || resize < crop || out_c < 3) { salve_fail("salve_bev_tiles: need 0 < crop <= resize, out_c >= 3"); return SALVE_ERR_BAD_ARG; }
-    if (out_format != SALVE_TILE_F32_NCHW && out_format != SALVE_TILE_F16_NHWC) { salve_fail("unknown tile format"); return SALVE_ERR_UNSUPPORTED; }
+    if (out_format != SALVE_TILE_F32_NCHW && out_format != SALVE_TILE_F16_NHWC && out_format != SALVE_TILE_U8X4) { salve_fail("unknown tile format"); return SALVE_ERR_UNSUPPORTED; }
     if (n_jobs > 65535) { salve_fail("at most 65535 tile jobs per call"); return SALVE_ERR_BAD_ARG; }
     dim3 g((crop * crop + 255) / 256, n_jobs);
     hipLaunchKernelGGL(bev_tile_kernel, g, dim3(256), 0, (hipStream_t)stream, bev, bev_w, jobs, coef_y, coef_x, resize, crop,
@@ -1226,7 +1236,7 @@ int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const sal
 
 int salve_bev_tile_pairs(const uint32_t* bev_a, const uint32_t* bev_b, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs_a,
                          const salve_tile_job_t* jobs_b, int32_t n_pairs, const int32_t* coef_y, const int32_t* coef_x, int32_t resize,
-                         int32_t crop, const float* lut, void* out, int32_t out_c, void* stream) {
+                         int32_t crop, const float* lut, void* out, int32_t out_c, int32_t b_pretiled, void* stream) {
     if (n_pairs == 0) return SALVE_OK;
     if (!bev_a || !bev_b || !jobs_a || !jobs_b || !coef_y || !coef_x || !lut || !out || n_pairs < 0 || bev_h <= 0 || bev_w <= 0) {
         salve_fail("salve_bev_tile_pairs: null pointer or bad size");
@@ -1238,7 +1248,7 @@ int salve_bev_tile_pairs(const uint32_t* bev_a, const uint32_t* bev_b, int32_t b
     const int xcd_group = 1;   // the workgroups of a pair on one XCD: its two BEV images are read through one L2 (round 3: -0.3 ms per 4096)
     dim3 g((unsigned)((xcd_group ? (n_pairs + 7) / 8 * 8 : n_pairs) * n_blocks));
     hipLaunchKernelGGL(bev_tile_pair_kernel, g, dim3(256), 0, (hipStream_t)stream, bev_a, bev_b, bev_w, jobs_a, jobs_b, coef_y, coef_x,
-                       resize, crop, lut, reinterpret_cast<uint16_t*>(out), out_c, n_pairs, n_blocks, xcd_group);
+                       resize, crop, lut, reinterpret_cast<uint16_t*>(out), out_c, n_pairs, n_blocks, xcd_group, b_pretiled ? 1 : 0);
     SALVE_HIP_CHECK(hipGetLastError());
     return SALVE_OK;
 }

@@ -73,7 +73,7 @@ class RenderVerifyPipeline:
         # streams = 3: the scatter of chunk i+2 (memory-side atomics, HBM) additionally runs under the densify of chunk
         # i+1 (LDS / VALU) on a stream of its own, with two rasteriser workspaces
         self.scatter_stream = torch.cuda.Stream(self.device) if (overlap and streams >= 3) else None
-        self.pano_rgb = self.pano_depth = self.ref_bev = self.ref_in_window = None
+        self.pano_rgb = self.pano_depth = self.ref_bev = self.ref_tiles = self.ref_in_window = None
         self.n_panos = 0
         # event bookkeeping of score(): running chunk number, last densify per workspace slot, last verifier per buffer set
         self._seq = 0
@@ -107,6 +107,9 @@ class RenderVerifyPipeline:
                 n = min(256, P * S - lo)
                 self.ras.render_counted(self.pano_rgb, self.pano_depth, hd[lo * _lib.HYP_DTYPE.itemsize:], n, self.ref_bev[lo:lo + n],
                                         self.ref_in_window[lo:lo + n])
+        # the identity images' Resize + Crop, once per (panorama, surface): every hypothesis that names the panorama as its second
+        # one then only normalises them (salve_bev_tile_pairs, b_pretiled)
+        self.ref_tiles = self.ras.pretile(self.ref_bev)
         # render_counted used workspace slot 0 on the current stream: later launches on other streams wait for this event
         self._panos_ready = torch.cuda.Event()
         self._panos_ready.record(torch.cuda.current_stream(self.device))
@@ -151,7 +154,7 @@ class RenderVerifyPipeline:
             "rank": rank,
             "rows": self.ras.upload_hypotheses(rows),
             "jobs1": self.ras.upload_tile_jobs(st(jobs1_bev), st(jobs1_slot), st(jobs1_chan)),
-            "jobs2": self.ras.upload_tile_jobs(st(jobs2_bev), st(jobs2_slot), st(jobs2_chan)),
+            "jobs2": self.ras.upload_tile_jobs(st(jobs2_bev), st(jobs2_slot), st(jobs2_chan), pretiled=True),
             "in_window": torch.zeros(N * S, dtype=torch.int32, device=self.device),  # posed renders IN RENDER ORDER, filled by score()
             "ready": torch.cuda.Event(),   # the tables are on the device: launches on other streams wait for it
         }
@@ -196,8 +199,8 @@ class RenderVerifyPipeline:
             e1.record()
         with tracing.range("salve.tiles"):
             # (jobs1[k] / jobs2[k] are the two halves of one surface's six channels of one sample: prepare())
-            self.ras.tile_pairs(bev, prepared["jobs1"][lo * S * jb:], self.ref_bev, prepared["jobs2"][lo * S * jb:], n * S, tiles,
-                                self.engine.in_channels)
+            self.ras.tile_pairs(bev, prepared["jobs1"][lo * S * jb:], self.ref_tiles, prepared["jobs2"][lo * S * jb:], n * S, tiles,
+                                self.engine.in_channels, pretiled=True)
 
     def _verify_chunk(self, buf: int, n: int, out: torch.Tensor, vtimers=None) -> None:
         e0 = e1 = None

@@ -268,10 +268,11 @@ class BevRasteriser:
         _lib.check(st, "salve_bev_export_u8")
         return out
 
-    def upload_tile_jobs(self, bev_index: Sequence[int], slot: Sequence[int], chan: Sequence[int]) -> torch.Tensor:
+    def upload_tile_jobs(self, bev_index: Sequence[int], slot: Sequence[int], chan: Sequence[int], pretiled: bool = False) -> torch.Tensor:
+        """Tile jobs naming image `bev_index` of a BEV array -- or, with pretiled, of an array of TILE_U8X4 images."""
         Hb, Wb = self.bev_hw
         j = np.zeros(len(slot), dtype=_lib.TILE_JOB_DTYPE)
-        j["bev_offset"] = np.asarray(bev_index, dtype=np.int64) * (Hb * Wb)
+        j["bev_offset"] = np.asarray(bev_index, dtype=np.int64) * ((self.crop * self.crop) if pretiled else (Hb * Wb))
         j["slot"] = np.asarray(slot, dtype=np.int32)
         j["chan"] = np.asarray(chan, dtype=np.int32)
         return torch.from_numpy(j.view(np.uint8)).to(self.device)
@@ -288,15 +289,23 @@ class BevRasteriser:
         _lib.check(st, "salve_bev_tiles")
         return out
 
+    def pretile(self, bev: torch.Tensor) -> torch.Tensor:
+        """int32 [n, H, W] BEV images -> int32 [n, crop, crop] resized + cropped images (TILE_U8X4), for `tile_pairs(pretiled=True)`."""
+        n = int(bev.shape[0])
+        out = torch.empty((n, self.crop, self.crop), dtype=torch.int32, device=self.device)
+        jobs = self.upload_tile_jobs(np.arange(n), np.arange(n), np.zeros(n, dtype=np.int64))
+        return self.tiles(bev, jobs, n, out, _lib.TILE_U8X4, 3)
+
     def tile_pairs(self, bev_a: torch.Tensor, jobs_a: torch.Tensor, bev_b: torch.Tensor, jobs_b: torch.Tensor, n_pairs: int,
-                   out: torch.Tensor, out_c: int) -> torch.Tensor:
-        """Both tiles of every early-fusion pair in one pass (fp16 NHWC; include/salve_hip.h: salve_bev_tile_pairs)."""
+                   out: torch.Tensor, out_c: int, pretiled: bool = False) -> torch.Tensor:
+        """Both tiles of every early-fusion pair in one pass (fp16 NHWC; include/salve_hip.h: salve_bev_tile_pairs).  pretiled:
+        `bev_b` is `pretile`'s output and `jobs_b` was uploaded with pretiled=True."""
         Hb, Wb = self.bev_hw
         with torch.cuda.device(self.device):
             st = self.lib.salve_bev_tile_pairs(
                 ctypes.c_void_p(bev_a.data_ptr()), ctypes.c_void_p(bev_b.data_ptr()), Hb, Wb, ctypes.c_void_p(jobs_a.data_ptr()),
                 ctypes.c_void_p(jobs_b.data_ptr()), n_pairs, ctypes.c_void_p(self.coef_y.data_ptr()), ctypes.c_void_p(self.coef_x.data_ptr()),
-                self.resize, self.crop, ctypes.c_void_p(self.lut.data_ptr()), ctypes.c_void_p(out.data_ptr()), out_c, self._stream(),
+                self.resize, self.crop, ctypes.c_void_p(self.lut.data_ptr()), ctypes.c_void_p(out.data_ptr()), out_c, 1 if pretiled else 0, self._stream(),
             )
         _lib.check(st, "salve_bev_tile_pairs")
         return out

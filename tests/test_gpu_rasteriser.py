@@ -149,6 +149,14 @@ def test_tile_pairs_equal_two_tile_calls(setup):
             torch.cuda.synchronize()
             assert torch.equal(got, ref), (out_c, swap)
             assert got[..., :6 * groups].abs().sum() > 0
+            # ... and with the second image resized + cropped beforehand (TILE_U8X4; what the pipeline does with the identity renders)
+            pre = ras.pretile(other)
+            jbp = ras.upload_tile_jobs([(2 * s + g + 1) % 4 for s in range(2) for g in range(groups)], [s for s in range(2) for g in range(groups)],
+                                       [6 * g + 3 * (1 - swap) for s in range(2) for g in range(groups)], pretiled=True)
+            got2 = torch.full((2, 224, 224, out_c), -3.0, dtype=torch.float16, device=ras.device)
+            ras.tile_pairs(bev, ja, pre, jbp, 2 * groups, got2, out_c, pretiled=True)
+            torch.cuda.synchronize()
+            assert torch.equal(got2, ref), ("pretiled", out_c, swap)
 
 
 def test_degenerate_inputs(setup):
