@@ -50,11 +50,12 @@ def bytes_per_render(pano_h: int, pano_w: int) -> int:
     return (pano_h - 2 * crop) * pano_w * (3 + 2) + 501 * 501 * 3
 
 
-def counted_traffic(key: str):
-    """(bytes per unit, source) of `key` from profiles/traffic.json, or (None, None)."""
+def counted_traffic(key: str, field: str = "bytes_per_unit"):
+    """(bytes per unit, source) of `key` from profiles/traffic.json, or (None, None).  bytes_per_unit = FETCH_SIZE x 2 + WRITE_SIZE
+    (the guide's gfx950 correction of the read counter) for BOTH rooflines; bytes_per_unit_raw_fetch = with FETCH_SIZE as counted."""
     try:
         e = json.loads(TRAFFIC_FILE.read_text())[key]
-        return float(e["bytes_per_unit"]), e["source"]
+        return float(e[field]), e["source"]
     except Exception:
         return None, None
 
@@ -258,6 +259,7 @@ def main() -> None:
         tflops = full_n * gflop / ver_ms  # GFLOP / ms = TFLOP/s
         shape = f"{pano_w}x{pano_h}/{'+'.join(surfaces)}/resnet{args.layers}/launch{full_n}"
         ras_traffic, ras_src = counted_traffic(f"rasteriser/{pano_w}x{pano_h}/launch{renders}")
+        ras_traffic_raw, _ = counted_traffic(f"rasteriser/{pano_w}x{pano_h}/launch{renders}", "bytes_per_unit_raw_fetch")
         ver_traffic, ver_src = counted_traffic(f"verifier/resnet{args.layers}-{6 * S}ch/launch{full_n}")
         ver_alg, _ = counted_traffic(f"verifier_algorithmic/resnet{args.layers}-{6 * S}ch")
         config5 = (pano_h, pano_w, S, args.layers) == (1024, 2048, 2, 152)
@@ -276,7 +278,8 @@ def main() -> None:
             # panorama index (bev_pano_index_kernel, once per panorama set at load_panos) is outside the step, like the uploads.
             "roofline": {"kernel": "rasteriser: bev_splat_kernel + bev_densify_kernel", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": None if ras_traffic is None else int(ras_traffic * renders), "traffic_source": ras_src,
+                         "traffic": None if ras_traffic is None else int(ras_traffic * renders),
+                         "traffic_raw_fetch": None if ras_traffic_raw is None else int(ras_traffic_raw * renders), "traffic_source": ras_src,
                          "launch_ms": round(ras_ms, 3), "scatter_ms": round(scat_ms, 3), "densify_ms": round(dens_ms, 3),
                          "launches_timed": len(vfull), "renders_per_launch": renders, "algorithmic_bytes_per_render": bpr},
             # the verifier against BOTH of its roofs: the dense fp16 MFMA peak (frac) and the HBM time of its activation traffic at

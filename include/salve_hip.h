@@ -48,6 +48,9 @@ typedef enum {
 #define SALVE_STATUS_BAD_HYPOTHESIS 4 /* bev scatter stage: a salve_bev_hyp_t row names a panorama outside [0, n_panos) or a surface
                                          other than 0 / 1 -- that render is an empty image */
 
+#define SALVE_STATUS_LAYOUT_THICKNESS 8 /* layout_rasterise: a segment of thickness >= 19 pixels (OpenCV draws its end caps as 20- / 72-gons,
+                                          which are not implemented) -- that segment is not drawn */
+
 /* Library / ABI version (SALVE_HIP_ABI_VERSION). */
 int salve_hip_version(void);
 /* Message of the last failing call on this thread ("" if none). */
@@ -187,14 +190,17 @@ int salve_resize_rgb_u8(const uint8_t* src, int32_t n, int32_t src_h, int32_t sr
  * The pixel rules are OpenCV 4.x's (modules/imgproc/src/drawing.cpp): fillPoly with its defaults for the polygon; for a segment
  * ThickLine with LINE_AA -- an anti-aliased convex quadrilateral (FillConvexPoly: LineAA along the edges, then spans) plus an
  * anti-aliased 12-gon end cap (EllipseEx / ellipse2Poly at 30 degrees) at either end, LineAA's filter and slope tables, every
- * anti-aliased pixel blended twice; thickness <= 1 is one LineAA.  cv2 is not installed here and the reference's tests pin none
- * of it: the restatement is in oracle/layout_oracle.py ("parity unpinned"), the kernel is bit-exact against it. */
+ * anti-aliased pixel blended twice; thickness <= 1 is one LineAA.  LIMIT: thickness < 19 pixels (the reference draws 8- and
+ * 2-pixel lines, bevparams.py:81-99); OpenCV gives thicker lines end caps at 18- / 5-degree steps, which are not implemented -- such
+ * a segment is left out and SALVE_STATUS_LAYOUT_THICKNESS is raised in `status` (device int32 status word or NULL).  cv2 is not
+ * installed here and the reference's tests pin none of it: the restatement is in oracle/layout_oracle.py ("parity unpinned"), the
+ * kernel is bit-exact against it. */
 typedef struct {
     int32_t n_poly, poly_off; /* vertex count and first vertex of this image's polygon in poly_xy */
     int32_t n_seg, seg_off;   /* segment count and first segment in segs */
 } salve_layout_t;
 int salve_layout_rasterise(const salve_layout_t* layouts, int32_t n, const int32_t* poly_xy, const int32_t* segs, int32_t img_h,
-                           int32_t img_w, uint32_t* out, void* stream);
+                           int32_t img_w, uint32_t* out, int32_t* status, void* stream);
 
 /* BEV uint32 -> uint8 [n, bev_h, bev_w, 3], the array render_bev_image returns (bev_rendering_utils.py:328). */
 int salve_bev_export_u8(const uint32_t* bev, int32_t n, int32_t bev_h, int32_t bev_w, uint8_t* out, void* stream);

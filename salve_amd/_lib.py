@@ -53,6 +53,7 @@ RESNET_NO_PROJ_FUSE, RESNET_NO_CHAIN, RESNET_CHAIN_EXPAND_ONLY, RESNET_CHAIN_16_
 STATUS_WALK_FAILED = 1
 STATUS_FP16_RANGE = 2
 STATUS_BAD_HYPOTHESIS = 4
+STATUS_LAYOUT_THICKNESS = 8
 
 
 class BevConfig(ctypes.Structure):
@@ -120,7 +121,7 @@ def load() -> ctypes.CDLL:
     lib.salve_remove_hallucinated.restype = ctypes.c_int
     lib.salve_bev_keys_from_pixels.argtypes = [ctypes.POINTER(BevConfig), vp, vp, i32, vp, vp, sz, vp]
     lib.salve_bev_keys_from_pixels.restype = ctypes.c_int
-    lib.salve_layout_rasterise.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp]
+    lib.salve_layout_rasterise.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp]
     lib.salve_layout_rasterise.restype = ctypes.c_int
     lib.salve_bev_export_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.salve_bev_export_u8.restype = ctypes.c_int
@@ -159,6 +160,8 @@ def check_status_word(word: int, what: str) -> None:
                             "not those of the fp32 network (a network without trained normalisation statistics does this)")
     if word & STATUS_BAD_HYPOTHESIS:
         raise SalveHipError(f"{what}: a render row names a panorama outside the uploaded batch (or an unknown surface); its image is empty")
+    if word & STATUS_LAYOUT_THICKNESS:
+        raise SalveHipError(f"{what}: a layout segment of 19 pixels or more was left out (its OpenCV end caps are not implemented)")
     if word:
         raise SalveHipError(f"{what}: device status word {word:#x}")
 

@@ -298,7 +298,8 @@ __device__ void thick_line_setup(SegRec& S, int x1, int y1, int x2, int y2, int 
 }
 
 __global__ __launch_bounds__(256) void layout_kernel(const salve_layout_t* __restrict__ layouts, const int32_t* __restrict__ poly_xy,
-                                                     const int32_t* __restrict__ segs, int H, int W, uint32_t* __restrict__ out) {
+                                                     const int32_t* __restrict__ segs, int H, int W, uint32_t* __restrict__ out,
+                                                     int32_t* __restrict__ status) {
     __shared__ SegRec seg[SEGC];
     const int img = blockIdx.y;
     const int tiles_x = (W + TILE - 1) / TILE;
@@ -341,6 +342,12 @@ __global__ __launch_bounds__(256) void layout_kernel(const salve_layout_t* __res
             const int reach = thickness / 2 + 3;
             S.active = !(max(q[0], q[2]) + reach < tx0 || min(q[0], q[2]) - reach > tx0 + TILE - 1 ||
                          max(q[1], q[3]) + reach < ty0 || min(q[1], q[3]) - reach > ty0 + TILE - 1);
+            // End caps of radius >= 10 pixels (thickness >= 19) are 20- and 72-gons in OpenCV (EllipseEx: 18- and 5-degree steps), which
+            // this kernel does not draw: such a segment is NOT drawn at all and the launch says so -- never a silent 12-gon.
+            if (((((long long)thickness << (XY_SHIFT - 1)) + (XY_ONE >> 1)) >> XY_SHIFT) >= 10) {
+                S.active = false;
+                if (status && blockIdx.x == 0) atomicOr(status, SALVE_STATUS_LAYOUT_THICKNESS);
+            }
             S.thin = thickness <= 1;
             if (S.active && !S.thin) thick_line_setup(S, q[0], q[1], q[2], q[3], thickness);
             if (S.active && S.thin) {
@@ -396,14 +403,14 @@ __global__ __launch_bounds__(256) void layout_kernel(const salve_layout_t* __res
 }  // namespace
 
 extern "C" int salve_layout_rasterise(const salve_layout_t* layouts, int32_t n, const int32_t* poly_xy, const int32_t* segs, int32_t img_h,
-                                      int32_t img_w, uint32_t* out, void* stream) {
+                                      int32_t img_w, uint32_t* out, int32_t* status, void* stream) {
     if (n == 0) return SALVE_OK;
     if (n < 0 || n > 65535 || !layouts || !out || img_h <= 0 || img_w <= 0 || img_h > 32000 || img_w > 32000) {
         salve_fail("salve_layout_rasterise: null pointer, bad size or more than 65535 images");
         return SALVE_ERR_BAD_ARG;
     }
     dim3 grid((unsigned)(((img_w + TILE - 1) / TILE) * ((img_h + TILE - 1) / TILE)), (unsigned)n);
-    hipLaunchKernelGGL(layout_kernel, grid, dim3(256), 0, (hipStream_t)stream, layouts, poly_xy, segs, img_h, img_w, out);
+    hipLaunchKernelGGL(layout_kernel, grid, dim3(256), 0, (hipStream_t)stream, layouts, poly_xy, segs, img_h, img_w, out, status);
     SALVE_HIP_CHECK(hipGetLastError());
     return SALVE_OK;
 }

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from salve_amd import _lib
+from salve_amd import _lib, status
 from salve_amd.common.bevparams import DEFAULT_METERS_PER_PX, BEVParams, get_line_width_by_resolution
 
 HOHO_S_ZIND_SCALE_FACTOR = 1.5
@@ -84,7 +84,7 @@ def rasterise_layouts(specs: Sequence[LayoutSpec], device, bev_params: Optional[
         for lo in range(0, n, MAX_LAYOUTS_PER_LAUNCH):
             m = min(MAX_LAYOUTS_PER_LAUNCH, n - lo)
             st = lib.salve_layout_rasterise(ctypes.c_void_p(d_rec.data_ptr() + lo * rec_bytes), m, ctypes.c_void_p(d_poly.data_ptr()),
-                                            ctypes.c_void_p(d_seg.data_ptr()), H, W, ctypes.c_void_p(out[lo:].data_ptr()),
+                                            ctypes.c_void_p(d_seg.data_ptr()), H, W, ctypes.c_void_p(out[lo:].data_ptr()), status.ptr(device),
                                             ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
             _lib.check(st, "salve_layout_rasterise")
     return out

@@ -79,6 +79,47 @@ def test_interp_of_a_half_occupied_image():
         assert np.array_equal(got, bo.interp_exact(pts, colr.astype(np.uint8), G, G)[0]), occ
 
 
+def test_triangle_queue_at_its_bound_on_regular_half_occupied_lattices():
+    """The ONE triangle queue of the densify kernel holds H W entries; its bound (every queued triangle holds a lattice point that
+    is not a site, so there are at most 2 (H W - n) of them, and 2 n triangles in all) is reached by REGULAR half-occupied
+    lattices: a checkerboard, every other column, every other row -- 125 k sites, (H - 1)(W - 1) = 250 000 triangles of
+    twice-the-area 2, every one queued, maximal co-circularity (each star resolves its cocircular quads by the perturbation on
+    its own).  Through the C ABI with the work counters: queued triangles <= H W, no status bit, and the interpolant is the
+    oracle's, bit for bit."""
+    import ctypes
+
+    from salve_amd import _lib, status
+    from salve_amd.common.bevparams import BEVParams
+    from salve_amd.rasteriser import BevRasteriser
+
+    G = 501
+    dev = torch.device("cuda:0")
+    ras = BevRasteriser(dev, bev_params=BEVParams(img_h=G - 1, img_w=G - 1, meters_per_px=1.0))
+    ras.cfg.out_flags = 3   # no flip, no mask: the plain interpolant
+    yy, xx = np.mgrid[0:G, 0:G]
+    status.check(dev, "before")
+    for name, m in (("checkerboard", (xx + yy) % 2 == 0), ("every other column", xx % 2 == 0), ("every other row", yy % 2 == 0)):
+        pts = np.stack([xx[m], yy[m]], 1)
+        col = np.stack([(xx[m] * 7 + yy[m] * 3) % 256, (xx[m] * 5 + 11) % 256, (yy[m] * 13) % 256], 1).astype(np.uint8)
+        xy = torch.from_numpy(np.ascontiguousarray(pts, dtype=np.int32)).to(dev)
+        rgb = torch.from_numpy(col).to(dev)
+        bev = torch.empty((1, G, G), dtype=torch.int32, device=dev)
+        ras.keys_from_pixels(xy, rgb, bev)
+        stats = torch.zeros((1, 8), dtype=torch.int32, device=dev)
+        ws = ras._workspace(1)
+        st = ras.lib.salve_bev_densify(ctypes.byref(ras.cfg), 1, ctypes.c_void_p(bev.data_ptr()), None, ctypes.c_void_p(stats.data_ptr()),
+                                       status.ptr(dev), ctypes.c_void_p(ws.data_ptr()), ws.numel(), None)
+        assert st == 0, ras.lib.salve_last_error()
+        torch.cuda.synchronize()
+        status.check(dev, name)      # raises on SALVE_STATUS_WALK_FAILED (a full queue sets it)
+        sv = stats.cpu().numpy()[0]
+        assert sv[0] == len(pts) and sv[5] == 0
+        assert 0 < sv[7] <= G * G, (name, sv)
+        print(f"{name}: {sv[0]} sites, {sv[7]} queued triangles of {G * G} queue entries, {sv[6]} hard sites")
+        got = ras.export_u8(bev)[0].cpu().numpy()
+        assert np.array_equal(got, bo.interp_exact(pts, col, G, G)[0]), name
+
+
 def test_config5_large_panos_two_surfaces_resnet152():
     """2048x1024 panoramas, floor + ceiling, ResNet-152 12-channel early fusion (BASELINE config 5, fp16)."""
     from salve_amd.models.early_fusion import EarlyFusionCEResnet

@@ -140,6 +140,41 @@ def test_layout_kernel_matches_oracle_bit_for_bit():
 
 
 @gpu
+def test_a_segment_too_thick_for_the_kernel_is_left_out_and_reported():
+    """Through the C ABI directly (what INTEGRATION.md advertises): a segment of 19 pixels or more -- OpenCV would give it end caps at
+    18- / 5-degree steps, which the kernel does not draw -- is NOT drawn and SALVE_STATUS_LAYOUT_THICKNESS is raised; the 8-pixel
+    segment next to it is drawn as always.  (The Python wrapper refuses such thicknesses before they reach the library.)"""
+    import ctypes
+
+    torch = pytest.importorskip("torch")
+    from salve_amd import _lib
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    H = W = 64
+    rec = np.zeros(2, dtype=_lib.LAYOUT_DTYPE)
+    rec[0]["n_seg"], rec[0]["seg_off"] = 1, 0     # image 0: one 8-pixel segment
+    rec[1]["n_seg"], rec[1]["seg_off"] = 2, 0     # image 1: the same segment + a 19-pixel one across it
+    segs = np.array([[10, 20, 50, 24, 0x00FF00, 8, 0, 0], [12, 50, 52, 40, 0x0000FF, 19, 0, 0]], dtype=np.int32)
+    d_rec = torch.from_numpy(rec.view(np.uint8)).to(dev)
+    d_seg = torch.from_numpy(segs).to(dev)
+    d_poly = torch.zeros((1, 2), dtype=torch.int32, device=dev)
+    out = torch.empty((2, H, W), dtype=torch.int32, device=dev)
+    word = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = lib.salve_layout_rasterise(ctypes.c_void_p(d_rec.data_ptr()), 2, ctypes.c_void_p(d_poly.data_ptr()), ctypes.c_void_p(d_seg.data_ptr()), H, W,
+                                    ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(word.data_ptr()), None)
+    torch.cuda.synchronize()
+    assert st == 0, lib.salve_last_error()
+    assert int(word.item()) == _lib.STATUS_LAYOUT_THICKNESS
+    assert out[0].any() and torch.equal(out[0], out[1])     # the thick segment left no pixel; the thin one is there
+    word.zero_()
+    st = lib.salve_layout_rasterise(ctypes.c_void_p(d_rec.data_ptr()), 1, ctypes.c_void_p(d_poly.data_ptr()), ctypes.c_void_p(d_seg.data_ptr()), H, W,
+                                    ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(word.data_ptr()), None)
+    torch.cuda.synchronize()
+    assert st == 0 and int(word.item()) == 0
+
+
+@gpu
 def test_layout_facade_pair_and_files(tmp_path):
     torch = pytest.importorskip("torch")
     from salve_amd.common.sim2 import Sim2

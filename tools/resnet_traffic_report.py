@@ -5,9 +5,10 @@ ops it executes (activations in + residual + out, fp16; weights once), the two r
 peak, bytes / 6.3 TB/s achievable HBM: /opt/skills/guides/MI355X_MICROARCH.md) and which binds, the counted HBM bytes
 (FETCH_SIZE x 2: on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, same guide; WRITE_SIZE as is; both
 in KiB units of 1024 B... the counter reports kilobytes), L2 hit rate and MFMA-busy.
-usage: resnet_traffic_report.py <dir> <batch>"""
+usage: resnet_traffic_report.py <dir> <batch> [title tag]"""
 import collections, csv, glob, json, sys
 d, B = sys.argv[1], int(sys.argv[2])
+TAG = sys.argv[3] if len(sys.argv) > 3 else "round 3, MI355X"
 VER = ("conv_igemm", "conv8_kernel", "conv_wide", "conv_pc", "bottleneck", "stem_pool", "maxpool", "avgpool", "expand_chain")
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
@@ -46,7 +47,7 @@ def op_cost(o):
         return 0.0, o["Hi"] * o["Wi"] * o["Cin"] * 2, o["Ho"] * o["Wo"] * o["Cout"] * 2, 0
     return 2.0 * o["Cin"] * o["Cout"], o["Hi"] * o["Wi"] * o["Cin"] * 2, o["Cout"] * 4, o["Cin"] * o["Cout"] * 4
 
-print(f"# Verifier, one ResNet forward at batch {B}: per-launch rooflines and counted HBM traffic (round 3, MI355X)")
+print(f"# Verifier, one ResNet forward at batch {B}: per-launch rooflines and counted HBM traffic ({TAG})")
 print()
 print("Durations: rocprofv3 --kernel-trace (no counters), last of three forwards.  alg = algorithmic: FLOP of the ops a launch executes; bytes =")
 print("activations read (input, residual, second source) + written, fp16, + the weights once.  t_mfma = FLOP / 2.5 PFLOP/s, t_hbm = bytes / 6.3 TB/s")
