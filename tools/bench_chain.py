@@ -1,5 +1,6 @@
 """Per-launch time of the expand_chain kernels in one forward at batch 4096 under development switches (GPU box).
-usage: bench_chain.py  (reads SALVE_CHAIN_DBG / SALVE_CHAIN_AHEAD / SALVE_RESNET_CHAIN from the environment)"""
+usage: bench_chain.py  (SALVE_RESNET_FLAGS: 64 = no chain, 128 = expand only, 256 = 16 waves, 512 = unsplit; SALVE_CHAIN_DBG works in an ablation build
+loaded with SALVE_HIP_LIB only)"""
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -19,4 +20,4 @@ t0 = time.perf_counter()
 for _ in range(3):
     eng.forward_nhwc(x)
 torch.cuda.synchronize()
-print(f"dbg={os.environ.get('SALVE_CHAIN_DBG', '0')} ahead={os.environ.get('SALVE_CHAIN_AHEAD', '2')} chain={os.environ.get('SALVE_RESNET_CHAIN', '2')}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms/forward")
+print(f"dbg={os.environ.get('SALVE_CHAIN_DBG', '0')} flags={os.environ.get('SALVE_RESNET_FLAGS', '0')}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms/forward")

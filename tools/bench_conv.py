@@ -1,6 +1,7 @@
 import os
 """Single-convolution timings of the verifier's shapes, one configuration of the convolution kernels per run (GPU box).
-usage: SALVE_CONV_WIDE=0|a|b|c|d python tools/bench_conv.py [batch]     prints one line per ResNet-50 shape:
+usage: SALVE_RESNET_FLAGS=1|2 python tools/bench_conv.py [batch]   (1 = conv_igemm_kernel only, 2 = the 8-phase kernel wherever it fits;
+       SALVE_CONV_WIDE=d|e|f selects a rejected kernel in an ablation build loaded with SALVE_HIP_LIB)     prints one line per ResNet-50 shape:
 time, TFLOP/s, and the checksum / max-abs of the output (to compare configurations with each other)."""
 import ctypes, os, sys, time
 from pathlib import Path
@@ -81,4 +82,4 @@ for name, cin, cout, k, stride, pad, hw, res, src2 in SHAPES:
     tot += us
     print(f"{name:30s} {us:8.1f} us  {flop / us / 1e6:7.0f} TFLOP/s   sum {float(out.double().sum()):.6e} absmax {float(out.abs().max()):.4f}", flush=True)
     lib.salve_resnet_destroy(h)
-print(f"total {tot:.1f} us  (SALVE_CONV_WIDE={os.environ.get('SALVE_CONV_WIDE', '')})")
+print(f"total {tot:.1f} us  (SALVE_RESNET_FLAGS={os.environ.get('SALVE_RESNET_FLAGS', '0')})")

@@ -1,5 +1,5 @@
 import os
-"""Stem (7x7/2 convolution + max-pool) alone at batch B (GPU box).  SALVE_STEM_FUSE=0|1, SALVE_HIP_LIB for ablation builds."""
+"""Stem (7x7/2 convolution + max-pool) alone at batch B (GPU box).  SALVE_RESNET_FLAGS=8: the un-fused stem; SALVE_HIP_LIB for ablation builds."""
 import ctypes, os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -36,4 +36,4 @@ torch.cuda.synchronize()
 per_buf = (need - 256) // 2 // 2
 view = ws[(-ws.data_ptr()) % 256:].view(torch.float16)
 out = view[per_buf: per_buf + B * 56 * 56 * 64].float()
-print(f"stem+pool B={B}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us  sum {float(out.double().sum()):.6e} (fuse={os.environ.get('SALVE_STEM_FUSE', '1')}, lib={os.environ.get('SALVE_HIP_LIB', 'default')})")
+print(f"stem+pool B={B}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us  sum {float(out.double().sum()):.6e} (flags={os.environ.get('SALVE_RESNET_FLAGS', '0')}, lib={os.environ.get('SALVE_HIP_LIB', 'default')})")

@@ -9,7 +9,7 @@ step() { local secs=$1 log=$2; shift 2; echo "== $*" >> "$OUT/steps.log"; timeou
 step 500 tests.log python -m pytest tests/test_gpu_conv8.py tests/test_gpu_verifier.py -m gpu -q -x -k "eight or alternative" || { tail -30 "$OUT/tests.log"; exit 1; }
 tail -1 "$OUT/tests.log"
 export SALVE_BENCH_ONLY=${ONLY:-l4.conv2,l3.conv1,l4.conv1,l3.conv2,l4.conv3}
-for m in 0 8 9; do
-  SALVE_CONV_WIDE=$m step 200 m$m.log python tools/bench_conv.py ${BATCH:-4096}
-  echo "-- SALVE_CONV_WIDE=$m"; grep -v amdgpu "$OUT/m$m.log"
+for m in 1 2; do
+  SALVE_RESNET_FLAGS=$m step 200 m$m.log python tools/bench_conv.py ${BATCH:-4096}
+  echo "-- SALVE_RESNET_FLAGS=$m (1 = conv_igemm_kernel only, 2 = the 8-phase kernel wherever it fits)"; grep -v amdgpu "$OUT/m$m.log"
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3: the expand_chain kernel -- bit-identity tests, then the forward at batch 4096 with SALVE_RESNET_CHAIN = 2 / 1 / 0
+# Round 3: the expand_chain kernel -- bit-identity tests, then the forward at batch 4096 with the chain kernel on / unsplit / off (SALVE_RESNET_FLAGS 0 / 512 / 64)
 # (alternating runs on one box), then a per-launch trace of the default.
 set -u
 export TMPDIR=/tmp
@@ -10,7 +10,7 @@ step() { local secs=$1 log=$2; shift 2; echo "== $*" >> "$OUT/steps.log"; timeou
 step 400 tests.log python -m pytest tests/test_gpu_verifier.py tests/test_gpu_conv8.py -m gpu -q -x || { tail -30 "$OUT/tests.log"; exit 1; }
 tail -1 "$OUT/tests.log"
 for i in 1 2; do
-  SALVE_RESNET_CHAIN=2 step 200 c2_$i.log python tools/bench_resnet.py 50 4096 && SALVE_CHAIN_SPLIT=0 step 200 c1_$i.log python tools/bench_resnet.py 50 4096 && SALVE_RESNET_CHAIN=0 step 200 c0_$i.log python tools/bench_resnet.py 50 4096 || exit 1
+  SALVE_RESNET_FLAGS=0 step 200 c2_$i.log python tools/bench_resnet.py 50 4096 && SALVE_RESNET_FLAGS=512 step 200 c1_$i.log python tools/bench_resnet.py 50 4096 && SALVE_RESNET_FLAGS=64 step 200 c0_$i.log python tools/bench_resnet.py 50 4096 || exit 1
 done
 for f in c2_1 c1_1 c0_1 c2_2 c1_2 c0_2; do echo $f; grep -v amdgpu "$OUT/$f.log"; done
 cd /tmp
