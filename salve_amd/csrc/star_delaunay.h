@@ -451,8 +451,12 @@ SD_FN void sd_share_best(const SdGrid& g, const SdEdge& e, SdBest* best, int* sh
 #endif
 }
 
+// First window of a sweeping query: the edge's bounding box widened by this many pixels.  Round 4, densify per 4096 renders
+// (bit-identical images): 6 -> 14.15-14.35 ms, 9 -> 13.9-14.1, 12 -> 14.05-14.16, 16 -> 14.3; with the circle cuts of the second sweep
+// applied in the windows too 16.0 (their square roots cost more than the candidates they save in a small window), and the circle
+// sweep WITHOUT its per-row chord cut 18.2: what a sweep costs is the candidates it evaluates.
 #ifndef SD_WINDOW_MARGIN
-#define SD_WINDOW_MARGIN 6
+#define SD_WINDOW_MARGIN 9
 #endif
 
 // Apex of the Delaunay triangle on side dir of the Delaunay edge s->a.  Returns false iff there is no site
