@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void bev_tile_pair_kernel(const uint32_t* __re
                                                             const int32_t* __restrict__ coef_y, const int32_t* __restrict__ coef_x, int resize,
                                                             int crop, const float* __restrict__ lut, uint16_t* __restrict__ out, int out_c,
                                                             int n_pairs, int n_blocks, int xcd_group, int b_pretiled) {
-    // (the workgroups of one pair read the same two BEV images: same id % 8 = same XCD = one L2 -- as in bev_scatter_kernel)
+    // (the workgroups of one pair read the same two BEV images: same id % 8 = same XCD = one L2 -- as in bev_splat_kernel)
     int job, blk;
     if (xcd_group) {
         const int id = blockIdx.x, s_ = id >> 3;

@@ -105,8 +105,15 @@ SD_FN void sd_cache_insert(const SdGrid& g, int ux, int uy, int vx, int vy, int 
 #define SDT_AMAX 5                                   // edge vectors with |ax|, |ay| <= SDT_AMAX
 #define SDT_SIDE (2 * SDT_AMAX + 1)
 #define SDT_NVEC (SDT_SIDE * SDT_SIDE)
-#define SDT_LEN 64                                   // candidates kept per vector (measured: 32 -> 64 removes 13 % of the hard sites, 128 adds nothing)
-#define SDT_REACH 48                                 // search radius when building (must dwarf the kept candidates)
+// Candidates kept per vector.  The LEAN walk (one site per lane, four candidates per step) uses the first SDT_LEAN_LEN of them
+// (measured: 32 -> 64 removes 13 % of the hard sites, 128 adds nothing); the GENERAL walk probes 64 per round with its whole
+// wavefront, so a long table is cheap there -- and an apex found in the table needs no sweep at all: the table order IS the exact
+// circle-growth order (round 4).
+#ifndef SDT_LEN
+#define SDT_LEN 512
+#endif
+#define SDT_LEAN_LEN 64
+#define SDT_REACH 64                                 // search radius when building (must dwarf the kept candidates)
 
 struct SdTable {
     int8_t off[SDT_NVEC][SDT_LEN][2];  // (dx, dy) relative to the edge's origin, best first
@@ -465,34 +472,34 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     SD_COUNT(apex);
     long long lap = SD_NOW();
     // 0. short edge: the pre-sorted candidate table answers with bitmap probes alone.  (Side -1 of s->a is side +1 of
-    //    a->s, so the table is entered with the edge reversed.)
-    if (g.tab != nullptr) {
-        const int ox = dir > 0 ? sx : ax, oy = dir > 0 ? sy : ay;
-        const int vx = dir > 0 ? ax - sx : sx - ax, vy = dir > 0 ? ay - sy : sy - ay;
-        if (vx >= -SDT_AMAX && vx <= SDT_AMAX && vy >= -SDT_AMAX && vy <= SDT_AMAX) {
-            const int8_t* row = g.tab + sdt_index(vx, vy) * (SDT_LEN * 2);
-            int hit = -1;
+    //    a->s, so the table is entered with the edge reversed.)  First the SDT_LEAN_LEN entries the lean walk knows -- one probe
+    //    per lane --, the rest of the table only after the cheaper answers (bounding box, triangle cache) have failed.
+    const int tox = dir > 0 ? sx : ax, toy = dir > 0 ? sy : ay;
+    const int tvx = dir > 0 ? ax - sx : sx - ax, tvy = dir > 0 ? ay - sy : sy - ay;
+    const bool tabled = g.tab != nullptr && tvx >= -SDT_AMAX && tvx <= SDT_AMAX && tvy >= -SDT_AMAX && tvy <= SDT_AMAX;
+    const int8_t* row = tabled ? g.tab + sdt_index(tvx, tvy) * (SDT_LEN * 2) : nullptr;
+    if (tabled) {
+        int hit = -1;
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (g.nlanes > 1) {  // one candidate per lane and round, the lowest occupied entry wins
-                for (int k0 = 0; k0 < SDT_LEN && hit < 0; k0 += g.nlanes) {
-                    const int k = k0 + g.lane;
-                    const bool b = k < SDT_LEN && sd_occupied(g, ox + row[2 * (k & (SDT_LEN - 1))], oy + row[2 * (k & (SDT_LEN - 1)) + 1]);
-                    const unsigned long long m = sd_group_ballot(g, b);
-                    if (m) hit = k0 + (int)__ffsll((long long)m) - 1;
-                }
-            } else
+        if (g.nlanes > 1) {  // one candidate per lane and round, the lowest occupied entry wins
+            for (int k0 = 0; k0 < SDT_LEAN_LEN && hit < 0; k0 += g.nlanes) {
+                const int k = k0 + g.lane;
+                const bool b = k < SDT_LEAN_LEN && sd_occupied(g, tox + row[2 * (k & (SDT_LEN - 1))], toy + row[2 * (k & (SDT_LEN - 1)) + 1]);
+                const unsigned long long m = sd_group_ballot(g, b);
+                if (m) hit = k0 + (int)__ffsll((long long)m) - 1;
+            }
+        } else
 #endif
-            {
-                for (int k = 0; k < SDT_LEN && hit < 0; k++)
-                    if (sd_occupied(g, ox + row[2 * k], oy + row[2 * k + 1])) hit = k;
-            }
-            SD_LAP(table, lap);
-            if (hit >= 0) {
-                SD_COUNT(apex_table);
-                *outx = ox + row[2 * hit];
-                *outy = oy + row[2 * hit + 1];
-                return true;
-            }
+        {
+            for (int k = 0; k < SDT_LEAN_LEN && hit < 0; k++)
+                if (sd_occupied(g, tox + row[2 * k], toy + row[2 * k + 1])) hit = k;
+        }
+        SD_LAP(table, lap);
+        if (hit >= 0) {
+            SD_COUNT(apex_table);
+            *outx = tox + row[2 * hit];
+            *outy = toy + row[2 * hit + 1];
+            return true;
         }
     }
     if (sd_side_is_empty(g, sx, sy, ax, ay, dir)) return false;
@@ -503,6 +510,54 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
         if (hit) {
             SD_COUNT(apex_cached);
             return hit == 1;
+        }
+    }
+    // 0b. the REST of the table (entries SDT_LEAN_LEN .. SDT_LEN - 1: the circle-growth order out to ~20 pixels).  An apex found
+    //     here needs no sweep at all -- the table order is exact -- and a sweeping query costs two sweeps and their merges.  All
+    //     rounds' table entries are fetched before any is used (one trip to the table, one to the bitmap), then the first
+    //     occupied entry in table order wins.
+    if (tabled && SDT_LEN > SDT_LEAN_LEN) {
+        int hit = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (g.nlanes > 1) {
+            constexpr int NR = (SDT_LEN - SDT_LEAN_LEN + 63) / 64;   // rounds of one candidate per lane (nlanes = 64 here; smaller groups loop)
+            if (g.nlanes == 64) {
+                int cxs[NR], cys[NR];
+                bool occb[NR];
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const int k = SDT_LEAN_LEN + 64 * r + g.lane;
+                    cxs[r] = k < SDT_LEN ? row[2 * (k & (SDT_LEN - 1))] : 127;
+                    cys[r] = k < SDT_LEN ? row[2 * (k & (SDT_LEN - 1)) + 1] : 127;
+                }
+#pragma unroll
+                for (int r = 0; r < NR; r++) occb[r] = (SDT_LEAN_LEN + 64 * r + g.lane) < SDT_LEN && sd_occupied(g, tox + cxs[r], toy + cys[r]);
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const unsigned long long m = sd_group_ballot(g, occb[r]);
+                    if (m != 0ull && hit < 0) hit = SDT_LEAN_LEN + 64 * r + (int)__ffsll((long long)m) - 1;
+                }
+            } else {
+                for (int k0 = SDT_LEAN_LEN; k0 < SDT_LEN && hit < 0; k0 += g.nlanes) {
+                    const int k = k0 + g.lane;
+                    const bool b = k < SDT_LEN && sd_occupied(g, tox + row[2 * (k & (SDT_LEN - 1))], toy + row[2 * (k & (SDT_LEN - 1)) + 1]);
+                    const unsigned long long m = sd_group_ballot(g, b);
+                    if (m) hit = k0 + (int)__ffsll((long long)m) - 1;
+                }
+            }
+        } else
+#endif
+        {
+            for (int k = SDT_LEAN_LEN; k < SDT_LEN && hit < 0; k++)
+                if (sd_occupied(g, tox + row[2 * k], toy + row[2 * k + 1])) hit = k;
+        }
+        SD_LAP(table, lap);
+        if (hit >= 0) {
+            SD_COUNT(apex_table);
+            *outx = tox + row[2 * hit];
+            *outy = toy + row[2 * hit + 1];
+            sd_cache_insert(g, ux, uy, vx, vy, *outx, *outy);
+            return true;
         }
     }
     const SdEdge edge = sd_edge(sx, sy, ax, ay, dir);

@@ -127,7 +127,7 @@ SD_FN int sdl_lean_step(SdLean& s, const SdGrid& g, Emit& emit) {
         if (b0 | b1 | b2 | b3) {
             px = ox + (b0 ? x0 : b1 ? x1 : b2 ? x2 : x3);
             py = oy + (b0 ? y0 : b1 ? y1 : b2 ? y2 : y3);
-        } else if (k + 1 < SDT_LEN / 4) {
+        } else if (k + 1 < SDT_LEAN_LEN / 4) {
             s.round = k + 1;  // same query, next four candidates
             return SDL_LEAN_CONTINUE;
         }
