@@ -46,6 +46,18 @@ def surfaces_for(modalities: Sequence[str]) -> List[str]:
     return MODALITY_SURFACES[key]
 
 
+def render_order(i1: np.ndarray, chunk: int) -> Tuple[np.ndarray, np.ndarray]:
+    """(order, rank): inside every chunk of `chunk` consecutive hypotheses the renders are issued in the order of their panorama
+    (a stable sort by i1) -- order[r] = the hypothesis rendered r-th, rank[j] = the position of hypothesis j.  Chunks keep their
+    hypotheses: launches, buffers and logits stay chunk for chunk where they were."""
+    i1 = np.asarray(i1).astype(np.int64)
+    N = len(i1)
+    order = np.concatenate([lo + np.argsort(i1[lo:lo + chunk], kind="stable") for lo in range(0, N, chunk)]) if N else np.zeros(0, np.int64)
+    rank = np.empty(N, dtype=np.int64)
+    rank[order] = np.arange(N)
+    return order, rank
+
+
 class RenderVerifyPipeline:
     def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: int = 512,
                  overlap: bool = True, streams: int = 3) -> None:
@@ -126,9 +138,7 @@ class RenderVerifyPipeline:
         N, S = len(hyp), len(self.surfaces)
         surf_ids = [SURFACES[s] for s in self.surfaces]
         i1 = np.asarray(hyp.i1).astype(np.int64)
-        order = np.concatenate([lo + np.argsort(i1[lo:lo + self.chunk], kind="stable") for lo in range(0, N, self.chunk)]) if N else np.zeros(0, np.int64)
-        rank = np.empty(N, dtype=np.int64)          # rank[j]: position of hypothesis j in the render order of the whole table
-        rank[order] = np.arange(N)
+        order, rank = render_order(i1, self.chunk)  # rank[j]: position of hypothesis j in the render order of the whole table
         rows = pack_hypotheses(np.repeat(i1[order], S), np.tile(surf_ids, N), np.repeat(np.asarray(hyp.R)[order], S, axis=0),
                                np.repeat(np.asarray(hyp.t)[order], S, axis=0), np.ones(N * S))
         j = np.arange(N)

@@ -420,3 +420,29 @@ def test_scatter_then_densify_equals_render_and_the_sparse_image_is_the_oracles(
         res, _ = oracle_render(panos, pi, surface, R, t, ap)
         assert np.array_equal(sparse[k], res["sparse"][::-1]), f"render {k}: sparse image"
         assert int(counts[k]) == res["img_xy"].shape[0]
+
+
+def test_panorama_index_follows_the_depth_tensor(setup):
+    """The pose-independent panorama index (block boxes) is built on first use and kept with the depth TENSOR OBJECT
+    (BevRasteriser.pano_index): a slice or a copy builds its own; a caller that overwrites depth maps in place calls
+    drop_pano_index first -- after which the render is that of a fresh upload, bit for bit."""
+    ras, panos, d_rgb, d_depth, hyp = setup
+    n = 3
+    hd = ras.upload_hypotheses(pack_hypotheses([0, 1, 0], [0, 0, 1], hyp.R[:n], hyp.t[:n], np.ones(n)))
+    first, _ = ras.render(d_rgb, d_depth, hd, n)
+    first = first.clone()
+    assert getattr(d_depth, "_salve_pano_index", None) is not None
+    # a copy of the tensors: its own index, the same images
+    again, _ = ras.render(d_rgb.clone(), d_depth.clone(), hd, n)
+    assert torch.equal(again, first)
+    # the two panoramas swapped IN PLACE: rows that named panorama 0 now see panorama 1's data
+    swapped_rgb, swapped_depth = d_rgb.flip(0).contiguous(), d_depth.flip(0).contiguous()
+    work_rgb, work_depth = d_rgb.clone(), d_depth.clone()
+    ras.render(work_rgb, work_depth, hd, n)                      # (index of the un-swapped content now hangs on work_depth)
+    work_rgb.copy_(swapped_rgb); work_depth.copy_(swapped_depth)
+    ras.drop_pano_index(work_depth)
+    got, _ = ras.render(work_rgb, work_depth, hd, n)
+    fresh, _ = ras.render(swapped_rgb, swapped_depth, hd, n)
+    torch.cuda.synchronize()
+    assert torch.equal(got, fresh) and not torch.equal(got, first)
+    ras.check("test_panorama_index_follows_the_depth_tensor")

@@ -325,3 +325,21 @@ def test_non_finite_weights_are_refused_when_the_program_is_packed():
     sd["resnet.layer3.0.conv1.weight"][3, 2, 1, 1] = float("nan")
     with pytest.raises(ValueError, match="non-finite"):
         hip_resnet.build_program(sd, 18)
+
+
+def test_render_order_sorts_by_panorama_inside_chunks_only():
+    """pipeline.render_order: renders are issued in panorama order INSIDE a chunk (L2 locality of the splat kernel); the tile jobs
+    find a hypothesis's render by its rank, so nothing a caller sees changes order."""
+    from salve_amd.pipeline import render_order
+
+    rng = np.random.default_rng(0)
+    for n, chunk in ((0, 8), (5, 8), (64, 16), (100, 32), (4096, 4096)):
+        i1 = rng.integers(0, 7, n)
+        order, rank = render_order(i1, chunk)
+        assert sorted(order.tolist()) == list(range(n)) and np.array_equal(rank[order], np.arange(n))
+        for lo in range(0, n, chunk):
+            blk = order[lo:lo + chunk]
+            assert blk.min() >= lo and blk.max() < lo + chunk          # a chunk keeps its hypotheses
+            assert (np.diff(i1[blk]) >= 0).all()                         # ... in panorama order
+            for p in np.unique(i1[blk]):                                 # ... stable: ties keep the table's order
+                assert (np.diff(blk[i1[blk] == p]) > 0).all()
