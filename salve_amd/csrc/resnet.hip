@@ -460,6 +460,27 @@ struct BottleneckArgs {
 
 constexpr int BN_THREADS = 512;  // 8 waves: two workgroups per CU give 4 waves per SIMD to hide the many short phases
 
+#ifndef SALVE_BN_ABL
+#define SALVE_BN_ABL 0   // timing-only builds of bottleneck_kernel (tools/build_bn_timers.sh): 1 = no output stores, 2 = every X row reads the zero page
+#endif
+#if defined(SALVE_BN_TIMERS)
+// development build (tools/bn_phase_time.py): where a tile's cycles go, wave 0 of every workgroup, s_memtime laps summed per phase:
+// [0] first X stage's wait + barrier [1] rest of GEMM 1 [2] t1 epilogue [3] first Wb stage's wait + barrier [4] rest of GEMM 2
+// [5] t2 epilogue [6] GEMM 3 [7] tiles; inside GEMM 3, per chunk: [8] weight chunk wait + barrier [9] MFMAs + epilogue into the
+// staging tile [10] barrier + stores + barrier
+__device__ unsigned long long bn_timers[2][16];
+#define BN_STAMP_(t) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define BN_T0() unsigned long long bn_t0_; BN_STAMP_(bn_t0_)
+#define BN_T(k) { unsigned long long t_; BN_STAMP_(t_) if (threadIdx.x == 0) atomicAdd(&bn_timers[PROJ ? 1 : 0][k], (k) == 7 ? 1ull : t_ - bn_t0_); bn_t0_ = t_; }
+#define BN_S0() unsigned long long bn_s0_; BN_STAMP_(bn_s0_)
+#define BN_S(k) { unsigned long long t_; BN_STAMP_(t_) if (threadIdx.x == 0) atomicAdd(&bn_timers[PROJ ? 1 : 0][k], t_ - bn_s0_); bn_s0_ = t_; }
+#else
+#define BN_T0()
+#define BN_T(k)
+#define BN_S0()
+#define BN_S(k)
+#endif
+
 // PROJ: the first block of layer 1 -- its input has MID channels (not 4 MID) and its shortcut is a 1x1 projection, which rides
 //       in GEMM 3 as MID more k: Y = relu([t2 | X] . [Wc | Ws]^T + (bc + bs)), the weight rows K-concatenated as the
 //       three-kernel path stores them (conv1x1_with_shortcut), 64 output channels at a time.
@@ -541,6 +562,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         res_swz[i] = (h >> 1) & 7;
     }
 
+    BN_T0();
     // ------------------------------------------------------------------ GEMM 1: t1 = relu(Xhalo . Wa^T + ba)
     {
         const uint16_t* rowp[M1 / 64];
@@ -548,7 +570,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         for (int i = 0; i < M1 / 64; i++) {
             const int h = row_base + 64 * i;
             const int hy = oy0 - 1 + h / HC, hx = ox0 - 1 + h % HC;
-            const bool ok = h < HALO && hy >= 0 && hy < p.H && hx >= 0 && hx < p.W;
+            const bool ok = h < HALO && hy >= 0 && hy < p.H && hx >= 0 && hx < p.W && !((SALVE_BN_ABL & 2) && p.B > 0);
             rowp[i] = ok ? ximg + ((long long)hy * p.W + hx) * CIN + chunk * 8 : nullptr;
         }
         const uint16_t* wrow = p.wa + (long long)row_base * CIN + chunk * 8;
@@ -584,6 +606,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             asm volatile("s_barrier" ::: "memory");
+            if (kt == 0) BN_T(0);
             const uint16_t* As = smem + (kt & 1) * ST1_E;
             const uint16_t* BsA = As + M1 * 64;
             if constexpr (!PROJ) {
@@ -615,6 +638,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             asm volatile("s_barrier" ::: "memory");  // everyone is done reading this buffer
         }
 #undef ISSUE_A
+        BN_T(1);
         ISSUE_WB(0);  // first Wb stage: lands while t1 is written (its buffer is behind t1)
         // t1 rows: MID halves = MID / 8 chunks of 16 bytes, chunk q of row h stored at slot q ^ swz(h)
 #pragma unroll
@@ -635,6 +659,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         }
     }
 
+    BN_T(2);
     // ------------------------------------------------------------------ GEMM 2: t2 = relu(3x3(t1) . Wb + bb)
     {
         f32x4 acc[RT][NT2];
@@ -652,6 +677,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (first stage: this wave's t1 stores)
             asm volatile("s_barrier" ::: "memory");
+            if (st == 0) BN_T(3);
             const uint16_t* Bst = BsB + (st & 1) * BSB_E;
 #pragma unroll
             for (int q = 0; q < STAGE_TILES; q++) {
@@ -681,6 +707,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
         }
+        BN_T(4);
 #pragma unroll
         for (int i = 0; i < RT; i++) {
             const int m = (wr * RT + i) * 16 + frag_row;  // output pixel of the tile, row-major
@@ -695,6 +722,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         }
     }
 #undef ISSUE_WB
+    BN_T(5);
 
     // ------------------------------------------------------------------ GEMM 3 (PROJ): Y = relu([t2 | X] . [Wc | Ws]^T + b)
     if constexpr (PROJ) {
@@ -712,6 +740,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             const uint16_t* src = ox < p.W ? ximg + ((long long)oy * p.W + ox) * CIN + chunk * 8 : p.zeros;
             __builtin_amdgcn_global_load_lds((global_cptr)src, (lds_ptr)(Xc + (wave * 8 + 64 * i) * 64), 16, 0, 0);
         }
+        BN_S0();
         for (int nc = 0; nc < C4 / 64; nc++) {
 #pragma unroll
             for (int q = 0; q < KP / 64; q++)
@@ -719,6 +748,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                                                  (lds_ptr)(Wp + q * 64 * 64 + (wave * 8) * 64), 16, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // (first chunk: also orders the t2 stores)
+            BN_S(8);
             f32x4 acc[RT][2];
 #pragma unroll
             for (int i = 0; i < RT; i++)
@@ -756,6 +786,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                         pack4<true>(amax, acc[i][j] + vec4(bias));
                 }
             }
+            BN_S(9);
             __syncthreads();
             uint16_t* yimg = p.y + (long long)b * p.H * p.W * C4;
 #pragma unroll
@@ -763,17 +794,19 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const int id = tid + it * BN_THREADS;
                 const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (ox < p.W)
+                if (ox < p.W && !((SALVE_BN_ABL & 1) && p.B > 0))
                     *reinterpret_cast<uint4*>(yimg + ((long long)oy * p.W + ox) * C4 + nc * 64 + ch * 8) =
                         *reinterpret_cast<const uint4*>(Cp + m * LDC_P + ch * 8);
             }
             __syncthreads();  // staging and weight chunk are reused by the next chunk
+            BN_S(10);
         }
     } else
     // ------------------------------------------------------------------ GEMM 3: Y = relu(t2 . Wc^T + bc + X)
     {
         constexpr int CH_PER_ROW = 128 / 8;
         constexpr int C_ITERS = (MO * CH_PER_ROW) / BN_THREADS;
+        BN_S0();
 #pragma unroll
         for (int nc = 0; nc < C4 / 128; nc++) {
             // Wc chunk: 128 output channels x MID, as KT_MID tiles of 128 rows x 64
@@ -785,6 +818,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                                                      (lds_ptr)(BsC + q * 128 * 64 + (wave * 8 + 64 * j) * 64), 16, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // (first chunk: also orders the t2 stores)
+            BN_S(8);
             f32x4 acc[RT][4];
 #pragma unroll
             for (int i = 0; i < RT; i++)
@@ -823,6 +857,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                     *cell = pack4<true>(amax, acc[i][j] + vec4(bias) + vec4(r));
                 }
             }
+            BN_S(9);
             __syncthreads();
             uint16_t* yimg = p.y + (long long)b * p.H * p.W * C4;
 #pragma unroll
@@ -830,13 +865,16 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const int id = tid + it * BN_THREADS;
                 const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (ox < p.W)
+                if (ox < p.W && !((SALVE_BN_ABL & 1) && p.B > 0))
                     *reinterpret_cast<uint4*>(yimg + ((long long)oy * p.W + ox) * C4 + nc * 128 + ch * 8) =
                         *reinterpret_cast<const uint4*>(Cs + m * LDC + ch * 8);
             }
             __syncthreads();  // staging and Wc tile are reused by the next chunk
+            BN_S(10);
         }
     }
+    BN_T(6);
+    BN_T(7);
     report_range(p.status, amax);
 }
 
@@ -916,6 +954,16 @@ bool check_op(const salve_resnet_op_t& o) {
 
 extern "C" {
 
+#if defined(SALVE_BN_TIMERS)
+// development build only: reads (and clears) bottleneck_kernel's phase timers: out[2][16], [0] the plain form, [1] the PROJ form
+int salve_debug_bn_timers(unsigned long long* out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bn_timers), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    unsigned long long zero[32] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(bn_timers), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+
 void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,
                           const void* weights_f16, size_t weights_bytes, const float* params_f32, size_t params_bytes,
                           const int32_t* ktab, size_t ktab_entries, int32_t flags) {
@@ -957,7 +1005,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
             if (a.op != SALVE_OP_CONV || b.op != SALVE_OP_MAXPOOL) continue;
             const bool shape = a.KH == 7 && a.KW == 8 && a.stride == 2 && a.pad == 3 && a.Cin == 8 && a.Cout == 64 && a.relu &&
                                a.res_buf == SALVE_NO_BUF && a.in2_buf == SALVE_NO_BUF && b.in_buf == a.out_buf && b.Cin == 64 &&
-                               a.Hi % 4 == 0 && a.Wi % 4 == 0 && a.Wi <= STEM_MAX_W && (a.Wi / 2) % 16 == 0 && (a.Hi / 4) % STEM_R == 0 &&
+                               a.Hi % 4 == 0 && a.Wi % 4 == 0 && a.Wi == STEM_W && (a.Hi / 4) % STEM_R == 0 &&
                                a.Ho == a.Hi / 2 && a.Wo == a.Wi / 2 && b.Ho == a.Hi / 4 && b.Wo == a.Wi / 4;
             bool dead = shape;   // nobody else may read the un-pooled convolution output
             for (size_t k = i + 2; dead && k < h->ops.size(); k++) {
@@ -1094,10 +1142,10 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.bias = h->d_params + o.b_off;
             a.y = buf(pool.out_buf);
             a.zeros = h->d_zeros;
-            a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status; a.xcd_contig = h->xcd_contig;
-            const long long grid = (long long)batch * ((o.Hi / 4) / STEM_R);
-            if (grid > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
-            hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)grid), dim3(STEM_THREADS), 0, s, a);
+            a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status;
+            const long long strips = (long long)batch * ((o.Hi / 4) / STEM_R);
+            const unsigned grid = (unsigned)(strips < h->n_cus ? strips : h->n_cus);   // persistent: one workgroup per CU, a contiguous range of strips each
+            hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(STEM_THREADS), 0, s, a);
             SALVE_HIP_CHECK(hipGetLastError());
             oi += 1;
             continue;
