@@ -322,10 +322,15 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     float amax = 0.f;
     float amin = 0.f;
     const float lo = p.relu ? 0.f : -65504.f;
+    // (all of the lane's biases in one batch: inside the loop below -- one basic block per tile column because of the residual
+    //  branch -- every column's load was followed by its own wait: NT round trips to the L2 per tile, one after the other; round 4)
+    float4 bias_j[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) bias_j[j] = *reinterpret_cast<const float4*>(p.bias + n0 + wc * WN + j * 16 + 4 * (lane >> 4));
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         const int ncol = wc * WN + j * 16 + 4 * (lane >> 4);  // this lane's 4 consecutive channels of tile column j
-        const float4 bias = *reinterpret_cast<const float4*>(p.bias + n0 + ncol);
+        const float4 bias = bias_j[j];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int mrow = wr * 64 + i * 16 + (lane & 15);
