@@ -465,6 +465,28 @@ struct BottleneckArgs {
 
 constexpr int BN_THREADS = 512;  // 8 waves: two workgroups per CU give 4 waves per SIMD to hide the many short phases
 
+#ifndef SALVE_STORE_POLICY
+#define SALVE_STORE_POLICY 0   // output stores of the streaming kernels: 0 plain, 1 sc1, 2 nt, 3 sc0 sc1, 4 sc1 nt (timing builds)
+#endif
+typedef __attribute__((__ext_vector_type__(4))) unsigned u32x4;
+// 16-byte store of an output that nobody reads before the next launch
+__device__ __forceinline__ void store16_stream(uint16_t* p, uint4 v) {
+#if SALVE_STORE_POLICY == 0
+    *reinterpret_cast<uint4*>(p) = v;
+#else
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+#if SALVE_STORE_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#elif SALVE_STORE_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#elif SALVE_STORE_POLICY == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#endif
+#endif
+}
+
 #ifndef SALVE_BN_ABL
 #define SALVE_BN_ABL 0   // timing-only builds of bottleneck_kernel (tools/build_bn_timers.sh): 1 = no output stores, 2 = every X row reads the zero page
 #endif
@@ -517,7 +539,10 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     constexpr int EC_P = T2_E + MO * 64 + 64 * (MID + CIN) + MO * LDC_P;    // PROJ: t2 | X centre tile | weight chunk | staging
     constexpr int EA = 2 * ST1_E, EB = T1_E + 2 * BSB_E, EC = PROJ ? EC_P : T2_E + BSC_E + CS_E;
     constexpr int SMEM_E = EA > EB ? (EA > EC ? EA : EC) : (EB > EC ? EB : EC);
-    __shared__ __attribute__((aligned(1024))) uint16_t smem[SMEM_E];
+#ifndef SALVE_BN_PAD_LDS
+#define SALVE_BN_PAD_LDS 0   // timing-only: extra LDS elements per workgroup (45056: one workgroup per CU instead of two)
+#endif
+    __shared__ __attribute__((aligned(1024))) uint16_t smem[SMEM_E + SALVE_BN_PAD_LDS];
     uint16_t* T1 = smem;
     uint16_t* T2 = smem;
     uint16_t* BsB = smem + T1_E;
@@ -800,8 +825,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
                 if (ox < p.W && !((SALVE_BN_ABL & 1) && p.B > 0))
-                    *reinterpret_cast<uint4*>(yimg + ((long long)oy * p.W + ox) * C4 + nc * 64 + ch * 8) =
-                        *reinterpret_cast<const uint4*>(Cp + m * LDC_P + ch * 8);
+                    store16_stream(yimg + ((long long)oy * p.W + ox) * C4 + nc * 64 + ch * 8, *reinterpret_cast<const uint4*>(Cp + m * LDC_P + ch * 8));
             }
             __syncthreads();  // staging and weight chunk are reused by the next chunk
             BN_S(10);
@@ -871,8 +895,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
                 if (ox < p.W && !((SALVE_BN_ABL & 1) && p.B > 0))
-                    *reinterpret_cast<uint4*>(yimg + ((long long)oy * p.W + ox) * C4 + nc * 128 + ch * 8) =
-                        *reinterpret_cast<const uint4*>(Cs + m * LDC + ch * 8);
+                    store16_stream(yimg + ((long long)oy * p.W + ox) * C4 + nc * 128 + ch * 8, *reinterpret_cast<const uint4*>(Cs + m * LDC + ch * 8));
             }
             __syncthreads();  // staging and Wc tile are reused by the next chunk
             BN_S(10);

@@ -1,11 +1,24 @@
 #!/bin/bash
-# Development: the library with bottleneck_kernel's phase timers (-DSALVE_BN_TIMERS, for tools/bn_phase_time.py) and its timing-only
-# builds (-DSALVE_BN_ABL=1: no output stores, 2: every X row reads the zero page, 3: both) into tools/_abl/.
+# Development: timing-only builds of bottleneck_kernel into tools/_abl/ (none of them is the product):
+#   libsalve_bn_timers.so        -DSALVE_BN_TIMERS: phase timers, read by tools/bn_phase_time.py
+#   libsalve_bn_abl{1,2,3}.so    -DSALVE_BN_ABL: no output stores / every X row reads the zero page / both
+#   libsalve_bn_1wg[_ablN].so    -DSALVE_BN_PAD_LDS=24576: one workgroup per CU instead of two (alone and with the switches above)
+#   libsalve_sp{1,2,3,4}.so      -DSALVE_STORE_POLICY: the fused block's output stores sc1 / nt / sc0 sc1 / sc1 nt
+# Time them with `SALVE_HIP_LIB=tools/_abl/<lib> python tools/bench_resnet.py 50 4096` (the forward's difference is the three launches').
 set -e
 cd "$(dirname "$0")/../salve_amd/csrc"
-mkdir -p ../../tools/_abl
-F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared"
-hipcc $F -DSALVE_BN_TIMERS -o ../../tools/_abl/libsalve_bn_timers.so *.hip &
-for a in 1 2 3; do hipcc $F -DSALVE_BN_ABL=$a -o ../../tools/_abl/libsalve_bn_abl$a.so *.hip & done
+mkdir -p ../../tools/_abl /tmp/bn_obj
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC"
+for f in bev_render layout; do hipcc $F -fno-slp-vectorize -c $f.hip -o /tmp/bn_obj/$f.o & done
+hipcc $F -c abi.hip -o /tmp/bn_obj/abi.o &
+wait
+build() { local tag=$1; shift; hipcc $F "$@" -c resnet.hip -o /tmp/bn_obj/r_$tag.o 2>/dev/null && hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_abl/libsalve_$tag.so /tmp/bn_obj/r_$tag.o /tmp/bn_obj/bev_render.o /tmp/bn_obj/layout.o /tmp/bn_obj/abi.o; }
+build bn_timers -DSALVE_BN_TIMERS &
+for a in 1 2 3; do build bn_abl$a -DSALVE_BN_ABL=$a & done
+wait
+build bn_1wg -DSALVE_BN_PAD_LDS=24576 &
+for a in 1 2 3; do build bn_1wg_abl$a -DSALVE_BN_PAD_LDS=24576 -DSALVE_BN_ABL=$a & done
+wait
+for pol in 1 2 3 4; do build sp$pol -DSALVE_STORE_POLICY=$pol & done
 wait
 ls -la ../../tools/_abl/
