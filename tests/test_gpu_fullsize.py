@@ -143,3 +143,139 @@ def test_benchmark_launch_shape_against_the_oracle():
         worst = max(worst, err)
         assert err <= 1e-3, f"hypothesis {j}: logits of the batch-4096 forward {got_logits[j]} vs oracle {logit_exp}"
     print(f"benchmark launch shape (4096 per launch, one stream): 32 hypotheses, BEV bit-exact, max |logit - oracle| {worst:.2e}")
+
+
+def test_config4_table_as_eight_serial_shards():
+    """BASELINE config 4's WORKLOAD on one GPU: the 32 768-row table in the 8 contiguous blocks of 4096 the 8 ranks would own
+    (reference work list scripts/render_dataset_bev.py:91-117; gather of the model outputs train_utils.py:214-215), every block
+    scored through RenderVerifyPipeline(chunk=4096) and collected with `gather_logits(force=True)` -- the RCCL
+    `all_gather_into_tensor` in a world of one.  The concatenation must equal one pass over the unsharded table bit for bit, and
+    16 random rows are checked against the oracle: BEV image bit for bit, logits absolute 1e-3."""
+    import torch.distributed as dist
+
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from salve_amd.pipeline import RenderVerifyPipeline, gather_logits
+    from _helpers import randomise_bn
+
+    N, G = 32768, 8
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    randomise_bn(model)
+    panos = [synthetic.make_pano(i) for i in range(N_PANOS)]
+    rgb, depth = np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos])
+    table = synthetic.make_hypotheses(N, N_PANOS, seed=0)
+    picked = np.random.default_rng(4).choice(N, 16, replace=False)
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=dev)
+    try:
+        with mp.get_context("spawn").Pool(8) as pool:
+            pending = pool.map_async(_oracle_pair_logits, [(table.i1[j], table.i2[j], table.R[j], table.t[j]) for j in picked])
+            pipe = RenderVerifyPipeline(model, dev, chunk=4096, overlap=False, streams=1)
+            pipe.load_panos(rgb, depth)
+            parts, bevs = [], {}
+            for r in range(G):
+                lo, hi = table.shard_bounds(N, r, G)
+                assert hi - lo == 4096
+                prepared = pipe.prepare(table.shard(r, G))
+                local = pipe.score(prepared)
+                torch.cuda.synchronize()
+                pipe.check(f"config 4, shard {r}")
+                assert pipe.valid_mask(prepared).all()
+                parts.append(gather_logits(local, 1, force=True).clone())     # RCCL, world of one
+                for j in picked[(picked >= lo) & (picked < hi)]:
+                    k = pipe.bev_index(prepared, int(j - lo))[1]
+                    bevs[int(j)] = pipe.ras.export_u8(pipe.bevs[0][k:k + 1]).cpu().numpy()[0]
+            sharded = torch.cat(parts, 0)
+            # one pass over the unsharded table (eight chunks of 4096 inside ONE score() call)
+            prepared = pipe.prepare(table)
+            whole = pipe.score(prepared)
+            torch.cuda.synchronize()
+            pipe.check("config 4, unsharded")
+            assert torch.isfinite(whole).all()
+            assert torch.equal(sharded, whole), "logits of the eight shards differ from one pass over the whole table"
+            got = sharded.cpu().numpy()
+            oracle = pending.get(timeout=1200)
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    worst = 0.0
+    for j, (bev_exp, logit_exp) in zip(picked, oracle):
+        assert np.array_equal(bevs[int(j)], bev_exp), f"row {j}: BEV image differs from the oracle"
+        err = float(np.abs(got[j] - logit_exp).max())
+        worst = max(worst, err)
+        assert err <= 1e-3, f"row {j}: logits {got[j]} vs oracle {logit_exp}"
+    print(f"config 4 workload (32768 rows as 8 serial shards of 4096 + world-1 RCCL gather): == unsharded pass bit for bit; "
+          f"16 rows vs oracle: BEV bit-exact, max |logit - oracle| {worst:.2e}")
+
+
+def _oracle_config5_hypothesis(args):
+    """(pool worker, CPU only) BASELINE config 5, one hypothesis: the four oracle renders (ceiling and floor of both 2048 x 1024
+    panoramas) -> (BEV images of the two posed renders, fp32 logits of the oracle's 12-channel ResNet-152 on the oracle's fp32 tiles)."""
+    i1, i2, R, t = args
+    import torch as th
+
+    th.set_num_threads(2)
+    from oracle import bev_oracle as bo
+    from oracle import resnet_oracle as ro
+    from salve_amd import synthetic as syn
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from _helpers import randomise_bn
+
+    th.manual_seed(0)
+    model = EarlyFusionCEResnet(152, False, 2, SimpleNamespace(modalities=["ceiling_rgb_texture", "floor_rgb_texture"])).eval()
+    randomise_bn(model)
+    p1, p2 = syn.make_pano(int(i1), 1024, 2048), syn.make_pano(int(i2), 1024, 2048)
+    bevs, tiles = [], []
+    for surface in ("ceiling", "floor"):   # channel order of the 4-tuple: zind_data.py:306-315
+        r1, r2 = bo.render_bev_pair(p1[0], p1[1], p2[0], p2[1], R, t, surface, mode="exact")
+        bevs.append(r1["bev"])
+        tiles += [bo.tile_from_bev(r1["bev"]), bo.tile_from_bev(r2["bev"])]
+    x = th.from_numpy(np.concatenate(tiles, 0))
+    with th.no_grad():
+        ref = ro.forward(model.state_dict(), 152, [c[None] for c in x.split(3)])
+    return bevs, ref[0].numpy()
+
+
+def test_config5_launch_shape_against_the_oracle():
+    """BASELINE config 5 at the shape `bench.py --pano-hw 1024x2048 --surfaces floor,ceiling --layers 152 --hyps 512 --panos 16
+    --chunk 512` launches: 512 hypotheses = 1024 renders per rasteriser launch over 2048 x 1024 panoramas (a splat grid of 16 k
+    workgroups), ResNet-152 with 12 input channels at batch 512 (where the 8-phase and the expand-chain kernels are selected).
+    8 sampled hypotheses end to end against the oracle: both posed BEV images bit for bit, logits absolute 1e-3."""
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from salve_amd.pipeline import RenderVerifyPipeline
+    from _helpers import randomise_bn
+
+    H, W, N, P = 1024, 2048, 512, 16
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(152, False, 2, SimpleNamespace(modalities=["ceiling_rgb_texture", "floor_rgb_texture"])).eval()
+    randomise_bn(model)
+    hyp = synthetic.make_hypotheses(N, P, seed=0)
+    picked = np.random.default_rng(15).choice(N, 8, replace=False)
+    with mp.get_context("spawn").Pool(8) as pool:
+        pending = pool.map_async(_oracle_config5_hypothesis, [(hyp.i1[j], hyp.i2[j], hyp.R[j], hyp.t[j]) for j in picked], chunksize=1)
+        panos = [synthetic.make_pano(i, H, W) for i in range(P)]
+        pipe = RenderVerifyPipeline(model, dev, pano_hw=(H, W), chunk=N, overlap=False, streams=1)
+        pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
+        prepared = pipe.prepare(hyp)
+        logits = pipe.score(prepared)
+        torch.cuda.synchronize()
+        pipe.check("config 5 launch shape")
+        assert pipe.valid_mask(prepared).all() and torch.isfinite(logits).all()
+        got_logits = logits.cpu().numpy()
+        got_bev = {}
+        for j in picked:
+            ck, k0 = pipe.bev_index(prepared, int(j))
+            got_bev[int(j)] = pipe.ras.export_u8(pipe.bevs[pipe.last_chunk_buffer[ck]][k0:k0 + 2]).cpu().numpy()   # ceiling, floor
+        oracle = pending.get(timeout=1500)
+    worst = 0.0
+    for j, (bevs_exp, logit_exp) in zip(picked, oracle):
+        for si, surface in enumerate(("ceiling", "floor")):
+            assert np.array_equal(got_bev[int(j)][si], bevs_exp[si]), f"hypothesis {j}, {surface}: BEV image differs from the oracle"
+        err = float(np.abs(got_logits[j] - logit_exp).max())
+        worst = max(worst, err)
+        assert err <= 1e-3, f"hypothesis {j}: logits {got_logits[j]} vs oracle {logit_exp}"
+    print(f"config 5 launch shape (512 hypotheses = 1024 renders per launch, ResNet-152 12-ch batch 512): 8 hypotheses, "
+          f"BEV bit-exact, max |logit - oracle| {worst:.2e}")
