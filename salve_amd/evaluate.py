@@ -81,16 +81,45 @@ def _summary(split: str, ckpt_fpath: str, cls: ClassAccuracyMeter, pr: Precision
             "precision": prec, "recall": rec, "mean_accuracy": macc}
 
 
+def batch_block(n_examples: int, batch_size: int, rank: int, world: int):
+    """(first example, one past the last example, first batch index, examples per rank [world]) of rank `rank` when the
+    ceil(n / batch_size) batches of an un-shuffled epoch are split into `world` contiguous blocks of WHOLE batches: batch
+    boundaries -- and with them the `batch_{i}.json` files -- are those of the single-process run."""
+    from salve_amd.synthetic import HypothesisTable
+
+    nb = -(-n_examples // batch_size) if n_examples else 0
+    bounds = [HypothesisTable.shard_bounds(nb, r, world) for r in range(world)]
+    counts = [max(0, min(hi * batch_size, n_examples) - lo * batch_size) for lo, hi in bounds]
+    blo, bhi = bounds[rank]
+    return blo * batch_size, min(bhi * batch_size, n_examples), blo, counts
+
+
+def sharded_loader(dataset, batch_size: int, rank: int, world: int):
+    """The un-fused driver's multi-GPU decomposition (the reference: nn.DataParallel scatters every batch and gathers the model
+    outputs, train_utils.py:214-215): one process per GPU instead, rank r reads and scores a contiguous block of whole batches.
+    Returns (DataLoader over the rank's examples, index of its first batch, examples per rank)."""
+    lo, hi, first_batch, counts = batch_block(len(dataset), batch_size, rank, world)
+    part = dataset if world == 1 else torch.utils.data.Subset(dataset, range(lo, hi))
+    return torch.utils.data.DataLoader(part, batch_size=batch_size, shuffle=False, num_workers=0, drop_last=False), first_batch, counts
+
+
 @torch.no_grad()
 def run_test_epoch(args, serialization_save_dir: str, ckpt_fpath: str, model, data_loader, split: str, save_viz: bool = False,
-                   serialize_predictions: bool = True) -> Dict[str, Any]:
-    """scripts/test.py:155-277.  Batches are (x1, x2[, x3, x4[, x5, x6]], is_match, fp0, fp1)."""
+                   serialize_predictions: bool = True, world: int = 1, rank: int = 0, first_batch: int = 0,
+                   counts: Optional[Sequence[int]] = None) -> Dict[str, Any]:
+    """scripts/test.py:155-277.  Batches are (x1, x2[, x3, x4[, x5, x6]], is_match, fp0, fp1).
+    world > 1 (`sharded_loader`): `data_loader` holds this rank's block of whole batches, `first_batch` the index of its first
+    one (every rank writes its own `batch_{i}.json` files -- the same files a single process writes), `counts` the examples per
+    rank; the predictions are collected with the path's ONE all-gather (pipeline.gather_logits) and every rank returns the
+    metrics of the whole split."""
     from salve_amd import train_utils
 
     if save_viz:
         raise RuntimeError("false-positive visualisation (matplotlib) is outside the accelerated path")
     cls, pr = ClassAccuracyMeter(args.num_ce_classes), PrecisionRecallMeter()
-    for i, example in enumerate(data_loader):
+    mine = []   # (y_hat, y_true) of this rank's examples, for the gather
+    dev = None
+    for i, example in enumerate(data_loader, start=first_batch):
         *xs, is_match, fp0, fp1 = example
         xs = list(xs) + [None] * (6 - len(xs))
         dev = xs[0].device if not torch.cuda.is_available() else torch.device("cuda")
@@ -102,22 +131,48 @@ def run_test_epoch(args, serialization_save_dir: str, ckpt_fpath: str, model, da
             from salve_amd import status
 
             status.check(dev, f"run_test_epoch, batch {i}")
-        cls.update(y_hat.cpu().numpy(), gt.reshape(-1).cpu().numpy())
-        pr.update(y_true=gt.reshape(-1).cpu().numpy(), y_hat=y_hat.cpu().numpy())
+        if world > 1:
+            mine.append(torch.stack([y_hat.float(), gt.reshape(-1).float()], 1))
+        else:
+            cls.update(y_hat.cpu().numpy(), gt.reshape(-1).cpu().numpy())
+            pr.update(y_true=gt.reshape(-1).cpu().numpy(), y_hat=y_hat.cpu().numpy())
         if serialize_predictions:
             save_edge_classifications_to_disk(serialization_save_dir, i, y_hat, gt.reshape(-1), probs, fp0, fp1)
+    if world > 1:
+        from salve_amd.pipeline import gather_logits
+
+        if counts is None:
+            raise RuntimeError("run_test_epoch with world > 1 needs `counts` (evaluate.sharded_loader)")
+        if dev is None:   # a rank without a batch still takes part in the collective
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        local = torch.cat(mine, 0) if mine else torch.zeros((0, 2), dtype=torch.float32, device=dev)
+        both = gather_logits(local, world, counts=list(counts)).cpu().numpy()
+        cls.update(both[:, 0].astype(np.int64), both[:, 1].astype(np.int64))
+        pr.update(y_true=both[:, 1].astype(np.int64), y_hat=both[:, 0].astype(np.int64))
     return _summary(split, ckpt_fpath, cls, pr)
 
 
-def evaluate_model(serialization_save_dir: str, ckpt_fpath: str, args, split: str, save_viz: bool = False) -> Dict[str, Any]:
-    """scripts/test.py:280-303: data loader -> model -> checkpoint -> run_test_epoch -> `{ckpt stem}.json` summary."""
+def evaluate_model(serialization_save_dir: str, ckpt_fpath: str, args, split: str, save_viz: bool = False, world: int = 1,
+                   rank: int = 0) -> Dict[str, Any]:
+    """scripts/test.py:280-303: data loader -> model -> checkpoint -> run_test_epoch -> `{ckpt stem}.json` summary.
+    world > 1: one process per GPU (torch.distributed initialised by the caller), every rank scores its block of whole batches
+    (`sharded_loader`), rank 0 writes the summary."""
     from salve_amd import train_utils
 
-    loader = train_utils.get_dataloader(args, split=split)
     model = train_utils.load_model_checkpoint(ckpt_fpath, train_utils.get_model(args), args)
-    metrics = run_test_epoch(args, serialization_save_dir, ckpt_fpath, model.eval(), loader, split, save_viz)
-    with open(f"{Path(ckpt_fpath).stem}.json", "w") as f:
-        json.dump(metrics, f, indent=4)
+    if world == 1:
+        loader = train_utils.get_dataloader(args, split=split)
+        metrics = run_test_epoch(args, serialization_save_dir, ckpt_fpath, model.eval(), loader, split, save_viz)
+    else:
+        from salve_amd.dataset.zind_data import ZindData
+
+        data = ZindData(split=split, transform=train_utils.get_img_transform_list(args, split), args=args)
+        loader, first_batch, counts = sharded_loader(data, args.batch_size, rank, world)
+        metrics = run_test_epoch(args, serialization_save_dir, ckpt_fpath, model.eval(), loader, split, save_viz, world=world, rank=rank,
+                                 first_batch=first_batch, counts=counts)
+    if rank == 0:
+        with open(f"{Path(ckpt_fpath).stem}.json", "w") as f:
+            json.dump(metrics, f, indent=4)
     return metrics
 
 

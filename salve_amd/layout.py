@@ -33,14 +33,42 @@ def world_to_pixels(bev_params: BEVParams, xy: np.ndarray) -> np.ndarray:
     return np.round(bev_params.bevimg_Sim2_world.transform_from(np.asarray(xy, dtype=np.float64).reshape(-1, 2))).astype(np.int64)
 
 
-def rasterise_layouts(specs: Sequence[LayoutSpec], device, bev_params: Optional[BEVParams] = None, render_mask: bool = True) -> torch.Tensor:
-    """-> int32 [n, H + 1, W + 1] device tensor holding 0x00BBGGRR, flipped vertically like the texture maps (the format
-    BevRasteriser.tiles / export_u8 take).  render_mask=False (a thin contour instead of the filled room, :128-136) draws the
-    room boundary as a polyline of a third of the W/D/O width."""
+class PackedLayouts:
+    """Flat device tables of n layout images (include/salve_hip.h: salve_layout_t records + shared vertex / segment arrays): what
+    `salve_layout_rasterise` reads.  Packed once on the host (`pack_layouts`), rasterised in any number of launches over slices of
+    the record table (the records carry absolute offsets into the shared arrays)."""
+
+    def __init__(self, rec: np.ndarray, poly: np.ndarray, seg: np.ndarray, hw: Tuple[int, int], device: torch.device) -> None:
+        self.n = len(rec)
+        self.hw = hw
+        self.device = device
+        self.rec = torch.from_numpy(rec.view(np.uint8)).to(device)
+        self.poly = torch.from_numpy(np.ascontiguousarray(poly)).to(device)
+        self.seg = torch.from_numpy(np.ascontiguousarray(seg)).to(device)
+
+    def rasterise(self, lo: int, n: int, out: torch.Tensor) -> torch.Tensor:
+        """Images [lo, lo + n) -> out (int32 [>= n, H, W], 0x00BBGGRR, flipped vertically like the texture maps) on the current stream."""
+        assert 0 <= lo and lo + n <= self.n and out.is_contiguous() and out.numel() >= n * self.hw[0] * self.hw[1]
+        lib = _lib.load()
+        rec_bytes = _lib.LAYOUT_DTYPE.itemsize
+        H, W = self.hw
+        with torch.cuda.device(self.device):
+            # salve_layout_rasterise takes at most 65535 images per call (one grid dimension)
+            for a in range(lo, lo + n, MAX_LAYOUTS_PER_LAUNCH):
+                m = min(MAX_LAYOUTS_PER_LAUNCH, lo + n - a)
+                st = lib.salve_layout_rasterise(ctypes.c_void_p(self.rec.data_ptr() + a * rec_bytes), m, ctypes.c_void_p(self.poly.data_ptr()),
+                                                ctypes.c_void_p(self.seg.data_ptr()), H, W, ctypes.c_void_p(out[a - lo:].data_ptr()), status.ptr(self.device),
+                                                ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+                _lib.check(st, "salve_layout_rasterise")
+        return out
+
+
+def pack_layouts(specs: Sequence[LayoutSpec], device, bev_params: Optional[BEVParams] = None, render_mask: bool = True) -> PackedLayouts:
+    """Host side of `rasterise_layouts`: metres -> integer pixels exactly as the reference does (x 1.5, `bevimg_Sim2_world`,
+    `np.round`: bev_rendering_utils.py:127, 149, 187-188, 214-215), packed into the kernel's tables and uploaded."""
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.SalveHipError("layout rasterisation needs a HIP device ('cuda:N'); there is no CPU path")
-    lib = _lib.load()
     bp = bev_params or BEVParams()
     H, W = bp.img_h + 1, bp.img_w + 1
     width = get_line_width_by_resolution(DEFAULT_METERS_PER_PX)
@@ -48,11 +76,13 @@ def rasterise_layouts(specs: Sequence[LayoutSpec], device, bev_params: Optional[
     rec = np.zeros(n, dtype=_lib.LAYOUT_DTYPE)
     polys: List[np.ndarray] = []
     segs: List[Tuple[int, ...]] = []
+    n_poly = 0
     for i, (room, wdos) in enumerate(specs):
         room_px = world_to_pixels(bp, np.asarray(room, dtype=np.float64) * HOHO_S_ZIND_SCALE_FACTOR)
-        rec[i]["poly_off"], rec[i]["seg_off"] = sum(len(p) for p in polys), len(segs)
+        rec[i]["poly_off"], rec[i]["seg_off"] = n_poly, len(segs)
         if render_mask:
             polys.append(room_px)
+            n_poly += len(room_px)
             rec[i]["n_poly"] = len(room_px)
         else:
             col = WHITE[0] | (WHITE[1] << 8) | (WHITE[2] << 16)
@@ -73,21 +103,16 @@ def rasterise_layouts(specs: Sequence[LayoutSpec], device, bev_params: Optional[
                          "(the reference draws 8- and 2-pixel lines: bevparams.get_line_width_by_resolution(0.02))")
     if max(int(np.abs(poly_np).max(initial=0)), int(np.abs(seg_np[:, :4]).max(initial=0))) > (1 << 24):
         raise ValueError("layout geometry more than 2^24 pixels away from the image: not a room layout")
-    d_rec = torch.from_numpy(rec.view(np.uint8)).to(device)
-    d_poly = torch.from_numpy(np.ascontiguousarray(poly_np)).to(device)
-    d_seg = torch.from_numpy(np.ascontiguousarray(seg_np)).to(device)
-    out = torch.empty((n, H, W), dtype=torch.int32, device=device)
-    rec_bytes = _lib.LAYOUT_DTYPE.itemsize
-    with torch.cuda.device(device):
-        # salve_layout_rasterise takes at most 65535 images per call (one grid dimension): a floor's hypotheses go in chunks;
-        # the records carry absolute offsets into the shared vertex / segment arrays, so a chunk is a slice of the record table
-        for lo in range(0, n, MAX_LAYOUTS_PER_LAUNCH):
-            m = min(MAX_LAYOUTS_PER_LAUNCH, n - lo)
-            st = lib.salve_layout_rasterise(ctypes.c_void_p(d_rec.data_ptr() + lo * rec_bytes), m, ctypes.c_void_p(d_poly.data_ptr()),
-                                            ctypes.c_void_p(d_seg.data_ptr()), H, W, ctypes.c_void_p(out[lo:].data_ptr()), status.ptr(device),
-                                            ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
-            _lib.check(st, "salve_layout_rasterise")
-    return out
+    return PackedLayouts(rec, poly_np, seg_np, (H, W), device)
+
+
+def rasterise_layouts(specs: Sequence[LayoutSpec], device, bev_params: Optional[BEVParams] = None, render_mask: bool = True) -> torch.Tensor:
+    """-> int32 [n, H + 1, W + 1] device tensor holding 0x00BBGGRR, flipped vertically like the texture maps (the format
+    BevRasteriser.tiles / export_u8 take).  render_mask=False (a thin contour instead of the filled room, :128-136) draws the
+    room boundary as a polyline of a third of the W/D/O width."""
+    packed = pack_layouts(specs, device, bev_params, render_mask)
+    out = torch.empty((packed.n, *packed.hw), dtype=torch.int32, device=packed.device)
+    return packed.rasterise(0, packed.n, out) if packed.n else out
 
 
 def layout_pair_specs(i2Ti1, floor_pose_graph, i1: int, i2: int) -> Tuple[LayoutSpec, LayoutSpec]:
@@ -101,3 +126,33 @@ def layout_pair_specs(i2Ti1, floor_pose_graph, i1: int, i2: int) -> Tuple[Layout
     wdos1 = [(w.type, i2Ti1.transform_from(np.asarray(w.vertices_local_2d, dtype=np.float64))) for w in list(n1.doors) + list(n1.windows) + list(n1.openings)]
     wdos2 = [(w.type, np.asarray(w.vertices_local_2d, dtype=np.float64)) for w in list(n2.doors) + list(n2.windows) + list(n2.openings)]
     return (room1, wdos1), (room2, wdos2)
+
+
+class FusedLayouts:
+    """The layout images the fused render -> verify pipeline needs for a hypothesis table (pipeline.RenderVerifyPipeline.prepare):
+    `posed[j]` = panorama i1[j]'s room and W/D/Os under hypothesis j's i2Ti1 (rasterize_room_layout_pair :82, :90), `identity[p]` =
+    panorama (store index) p's own layout (:96), the same for every hypothesis that names p as its second panorama."""
+
+    def __init__(self, posed: Sequence[LayoutSpec], identity: Sequence[LayoutSpec]) -> None:
+        self.posed, self.identity = list(posed), list(identity)
+
+    @classmethod
+    def from_pose_graph(cls, table, pano_ids: Sequence[int], floor_pose_graph, scales: Optional[Sequence[float]] = None) -> "FusedLayouts":
+        """table: HypothesisTable whose i1 / i2 index `pano_ids` (ingest.PanoStore order); scales: the hypotheses' Sim(2) scales
+        (default 1: alignment hypotheses are SE(2), export_alignment_hypotheses.py)."""
+        from salve_amd.common.sim2 import Sim2
+
+        posed = []
+        for j in range(len(table)):
+            S = Sim2(table.R[j], table.t[j], 1.0 if scales is None else float(scales[j]))
+            posed.append(layout_pair_specs(S, floor_pose_graph, int(pano_ids[int(table.i1[j])]), int(pano_ids[int(table.i2[j])]))[0])
+        close = lambda v: np.vstack([np.asarray(v, dtype=np.float64), np.asarray(v, dtype=np.float64)[0].reshape(-1, 2)])
+        identity = []
+        for pid in pano_ids:
+            nd = floor_pose_graph.nodes.get(int(pid)) if hasattr(floor_pose_graph.nodes, "get") else floor_pose_graph.nodes[int(pid)]
+            if nd is None:    # a panorama no hypothesis names as its second one may be missing from the graph: an empty image
+                identity.append((np.zeros((0, 2)), []))
+                continue
+            identity.append((close(nd.room_vertices_local_2d),
+                             [(w.type, np.asarray(w.vertices_local_2d, dtype=np.float64)) for w in list(nd.doors) + list(nd.windows) + list(nd.openings)]))
+        return cls(posed, identity)

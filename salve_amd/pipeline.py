@@ -36,6 +36,10 @@ MODALITY_SURFACES = {
     ("floor_rgb_texture",): ["floor"],
     ("ceiling_rgb_texture",): ["ceiling"],
     ("ceiling_rgb_texture", "floor_rgb_texture"): ["ceiling", "floor"],
+    # the rasterised-layout modality (early_fusion.py:24-32, 59-60): its two images follow the texture maps' channels
+    # (zind_data.py:26: pano 1 ceiling, pano 2 ceiling, pano 1 floor, pano 2 floor, pano 1 layout, pano 2 layout)
+    ("layout",): [],
+    ("ceiling_rgb_texture", "floor_rgb_texture", "layout"): ["ceiling", "floor"],
 }
 
 
@@ -67,6 +71,7 @@ class RenderVerifyPipeline:
         status.check(self.device, "a launch issued before this RenderVerifyPipeline was created")
         self.model = model
         self.surfaces = surfaces_for(model.modalities)
+        self.has_layout = "layout" in set(model.modalities)
         self.engine = model.compiled(self.device)
         self.ras = BevRasteriser(self.device, pano_hw=pano_hw)
         self.chunk = chunk
@@ -81,6 +86,8 @@ class RenderVerifyPipeline:
         self.tile_bufs = [torch.zeros((chunk, self.ras.crop, self.ras.crop, self.engine.in_channels), dtype=torch.float16,
                                       device=self.device) for _ in range(self.nbuf)]
         self.bev, self.tiles = self.bevs[0], self.tile_bufs[0]
+        # layout modality: the posed layout images of a chunk (salve_layout_rasterise), one per hypothesis
+        self.layout_bevs = [torch.empty((chunk, Hb, Wb), dtype=torch.int32, device=self.device) for _ in range(self.nbuf)] if self.has_layout else None
         self.render_stream = torch.cuda.Stream(self.device) if overlap else None
         # streams = 3: the scatter of chunk i+2 (memory-side atomics, HBM) additionally runs under the densify of chunk
         # i+1 (LDS / VALU) on a stream of its own, with two rasteriser workspaces
@@ -106,6 +113,8 @@ class RenderVerifyPipeline:
         self.pano_rgb, self.pano_depth = rgb_dev.contiguous(), depth_dev.contiguous()
         P = self.n_panos = int(rgb_dev.shape[0])
         S = len(self.surfaces)
+        if S == 0:   # layout only: no texture map is rendered, the panoramas are not read
+            return
         idx = np.repeat(np.arange(P), S)
         surf = np.tile([SURFACES[s] for s in self.surfaces], P)
         h = pack_hypotheses(idx, surf, np.tile(np.eye(2, dtype=np.float32), (P * S, 1, 1)), np.zeros((P * S, 2), np.float32),
@@ -128,8 +137,11 @@ class RenderVerifyPipeline:
         self._densified[0] = self._panos_ready
 
     # ------------------------------------------------------------------ hypotheses
-    def prepare(self, hyp: HypothesisTable):
+    def prepare(self, hyp: HypothesisTable, layouts=None):
         """Upload the render table and the tile job tables of a hypothesis shard (once, outside the timed loop).
+        `layouts` (salve_amd.layout.FusedLayouts; required iff the model's modalities include "layout"): the posed layout of
+        panorama i1 per hypothesis and the own layout of every panorama -- the geometry is posed on the host exactly as
+        layout.py / the reference do (bev_rendering_utils.py:82, 90), the pixels are drawn per chunk by salve_layout_rasterise.
 
         Inside every chunk the renders are issued in the order of their panorama (a stable sort by i1): the workgroups of
         consecutive renders run side by side, and those of one panorama then read its depth blocks, box table and colours
@@ -168,6 +180,21 @@ class RenderVerifyPipeline:
             "in_window": torch.zeros(N * S, dtype=torch.int32, device=self.device),  # posed renders IN RENDER ORDER, filled by score()
             "ready": torch.cuda.Event(),   # the tables are on the device: launches on other streams wait for it
         }
+        if self.has_layout:
+            from salve_amd import layout as layout_mod
+
+            if layouts is None or len(layouts.posed) != N:
+                raise RuntimeError('the "layout" modality needs `layouts` (salve_amd.layout.FusedLayouts) with one posed layout per hypothesis')
+            if N and int(np.max(hyp.i2)) >= len(layouts.identity):
+                raise RuntimeError("a hypothesis names a panorama without an identity layout")
+            # pano i2's own layout does not depend on the hypothesis: drawn, resized and cropped once per panorama (like the
+            # identity texture maps), then only normalised by the pair kernel
+            ident = layout_mod.rasterise_layouts(layouts.identity, self.device)
+            prepared["layout_ref_tiles"] = self.ras.pretile(ident)
+            prepared["layouts"] = layout_mod.pack_layouts(layouts.posed, self.device)   # hypothesis order: image j of the table
+            base = 6 * S
+            prepared["jobsL1"] = self.ras.upload_tile_jobs(slot, slot, base + 3 * swap)
+            prepared["jobsL2"] = self.ras.upload_tile_jobs(np.asarray(hyp.i2).astype(np.int64), slot, base + 3 * (1 - swap), pretiled=True)
         prepared["ready"].record(torch.cuda.current_stream(self.device))
         return prepared
 
@@ -189,6 +216,8 @@ class RenderVerifyPipeline:
 
     def _scatter_chunk(self, prepared, lo: int, n: int, buf: int, slot: int, timers=None) -> None:
         S = len(self.surfaces)
+        if S == 0:
+            return
         self.ras.ws_slot = slot
         _, e1 = self._timed(timers, n * S, "scatter")
         with tracing.range("salve.scatter"):
@@ -201,16 +230,23 @@ class RenderVerifyPipeline:
         S = len(self.surfaces)
         jb = _lib.TILE_JOB_DTYPE.itemsize
         bev, tiles = self.bevs[buf], self.tile_bufs[buf]
-        self.ras.ws_slot = slot
-        _, e1 = self._timed(timers, n * S, "densify")  # benchmark: HIP events on the stream the kernel is launched on
-        with tracing.range("salve.densify"):
-            self.ras.densify(n * S, bev)
-        if e1 is not None:
-            e1.record()
-        with tracing.range("salve.tiles"):
-            # (jobs1[k] / jobs2[k] are the two halves of one surface's six channels of one sample: prepare())
-            self.ras.tile_pairs(bev, prepared["jobs1"][lo * S * jb:], self.ref_tiles, prepared["jobs2"][lo * S * jb:], n * S, tiles,
-                                self.engine.in_channels, pretiled=True)
+        if S > 0:
+            self.ras.ws_slot = slot
+            _, e1 = self._timed(timers, n * S, "densify")  # benchmark: HIP events on the stream the kernel is launched on
+            with tracing.range("salve.densify"):
+                self.ras.densify(n * S, bev)
+            if e1 is not None:
+                e1.record()
+            with tracing.range("salve.tiles"):
+                # (jobs1[k] / jobs2[k] are the two halves of one surface's six channels of one sample: prepare())
+                self.ras.tile_pairs(bev, prepared["jobs1"][lo * S * jb:], self.ref_tiles, prepared["jobs2"][lo * S * jb:], n * S, tiles,
+                                    self.engine.in_channels, pretiled=True)
+        if self.has_layout:
+            with tracing.range("salve.layout"):
+                lbev = self.layout_bevs[buf]
+                prepared["layouts"].rasterise(lo, n, lbev)
+                self.ras.tile_pairs(lbev, prepared["jobsL1"][lo * jb:], prepared["layout_ref_tiles"], prepared["jobsL2"][lo * jb:], n, tiles,
+                                    self.engine.in_channels, pretiled=True)
 
     def _verify_chunk(self, buf: int, n: int, out: torch.Tensor, vtimers=None) -> None:
         e0 = e1 = None
@@ -251,7 +287,8 @@ class RenderVerifyPipeline:
             with torch.cuda.stream(ss):
                 if ss is not main:
                     ss.wait_event(prepared["ready"])
-                    ss.wait_event(self._panos_ready)
+                    if self._panos_ready is not None:
+                        ss.wait_event(self._panos_ready)
                 if self._densified[slot] is not None:
                     # the densify + tile kernels that used this workspace slot are done -- and with them the last reader of the
                     # BEV buffer the scatter is about to write its sparse images into (buffer set == slot whenever the
@@ -281,6 +318,8 @@ class RenderVerifyPipeline:
         at least one point inside the BEV window (bev_rendering_utils.py:279-280, 464-466, 623-627).  Call after score();
         synchronises."""
         S = len(self.surfaces)
+        if S == 0:   # layout only: rasterize_room_layout_pair always returns both images (bev_rendering_utils.py:48-101)
+            return np.ones(prepared["n"], dtype=bool)
         posed = prepared["in_window"].view(-1, S).cpu().numpy()[prepared["rank"]] > 0
         ident = self.ref_in_window.view(-1, S).cpu().numpy()[prepared["i2"]] > 0
         return (posed & ident).all(axis=1)
@@ -290,18 +329,28 @@ class RenderVerifyPipeline:
         status.check(self.device, what)
 
 
-def gather_logits(local: torch.Tensor, world: int, total: Optional[int] = None, force: bool = False) -> torch.Tensor:
+def gather_logits(local: torch.Tensor, world: int, total: Optional[int] = None, force: bool = False,
+                  counts: Optional[Sequence[int]] = None) -> torch.Tensor:
     """The path's only collective: one all-gather of the per-rank fp32 logits (mirrors DataParallel's gather of the model
     outputs, reference train_utils.py:214-215).  Shards of a contiguous block split differ by at most one row
     (HypothesisTable.shard_bounds), so every rank pads its block to ceil(total / world) rows for the single
     `all_gather_into_tensor` and the padding is dropped afterwards.  `total` = rows of the whole table (default: every
     rank holds local.shape[0] rows).  `force`: run the collective even in a world of one (bench.py --force-dist: the RCCL
-    path on a single GPU)."""
+    path on a single GPU).  `counts` (instead of `total`): the rows every rank holds, for blocks that are not the table's block
+    split (evaluate.run_test_epoch: blocks of whole batches) -- every rank pads to max(counts)."""
     if world == 1 and not force:
         return local
     import torch.distributed as dist
 
     n_local, C = int(local.shape[0]), int(local.shape[1])
+    if counts is not None:
+        assert len(counts) == world and n_local == int(counts[dist.get_rank()]), (counts, n_local)
+        per = max(1, max(int(c) for c in counts))
+        buf = torch.zeros((per, C), dtype=local.dtype, device=local.device)
+        buf[:n_local] = local
+        out = torch.empty((world * per, C), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, buf)
+        return torch.cat([out[r * per: r * per + int(counts[r])] for r in range(world)], 0)
     if total is None:
         total = n_local * world
     per = -(-total // world)

@@ -131,17 +131,26 @@ def _render_floor_layouts(hyps, img_fpaths: Dict[int, str], layout_save_root: st
 
 def render_pairs(num_processes: int, depth_save_root: str, bev_save_root: str, raw_dataset_dir: str, hypotheses_save_root: str,
                  layout_save_root: Optional[str], render_modalities: List[str], split: Optional[str], building_id: Optional[str],
-                 multiprocess_building_panos: bool = False, device=None) -> int:
+                 multiprocess_building_panos: bool = False, device=None, rank: int = 0, world: int = 1) -> int:
     """All floors of a split's buildings, or of one building (scripts/render_dataset_bev.py:120-191): exactly one of
-    `split` / `building_id`; building 1348 is skipped (two panoramas share an id, :160-162)."""
+    `split` / `building_id`; building 1348 is skipped (two panoramas share an id, :160-162).
+    world > 1: one process per GPU.  The reference hands its (building, floor) work list to a multiprocessing.Pool
+    (`p.starmap(render_building_floor_pairs, args)`, :186-188); here rank r takes items r, r + world, ... of the same list (round
+    robin: buildings differ a lot in size, neighbours in the sorted list less so) and writes their files -- the items are
+    independent, nothing is exchanged.  Returns the number of JPEG files THIS rank wrote."""
     if building_id is not None and split is not None:
         raise ValueError("Either `split` or `building_id` should be provided, but not both.")
-    building_ids = sorted(DATASET_SPLITS[split]) if split is not None else [building_id]
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside a world of {world}")
     written = 0
-    for bid in building_ids:
-        if bid == "1348":
-            continue
-        for floor_id in available_floors(hypotheses_save_root, bid):
-            written += render_building_floor_pairs(depth_save_root, bev_save_root, hypotheses_save_root, raw_dataset_dir, bid, floor_id,
-                                                   layout_save_root, render_modalities, multiprocess_building_panos, num_processes, device)
+    for bid, floor_id in floor_work_list(hypotheses_save_root, split, building_id)[rank::world]:
+        written += render_building_floor_pairs(depth_save_root, bev_save_root, hypotheses_save_root, raw_dataset_dir, bid, floor_id,
+                                               layout_save_root, render_modalities, multiprocess_building_panos, num_processes, device)
     return written
+
+
+def floor_work_list(hypotheses_save_root: str, split: Optional[str], building_id: Optional[str]) -> List[Tuple[str, str]]:
+    """The (building, floor) items of scripts/render_dataset_bev.py:151-184 in its order: buildings sorted, 1348 left out,
+    floors in the order `available_floors` lists them."""
+    building_ids = sorted(DATASET_SPLITS[split]) if split is not None else [building_id]
+    return [(bid, floor_id) for bid in building_ids if bid != "1348" for floor_id in available_floors(hypotheses_save_root, bid)]

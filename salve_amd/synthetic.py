@@ -191,3 +191,12 @@ def trained_looking_batchnorm(model, seed: int = 0) -> None:
             m.bias.data = 0.1 * torch.randn(m.num_features, generator=g)
             m.running_mean.data = 0.1 * torch.randn(m.num_features, generator=g)
             m.running_var.data = 0.6 + 0.8 * torch.rand(m.num_features, generator=g)
+
+
+def trained_looking_head(model, scale: float = 30.0) -> None:
+    """Scale the classifier head so that the logits have the magnitude a trained SALVe verifier emits (|logit| of several units:
+    its softmax outputs are mostly above 0.9, scripts/test.py:217-229) while the trunk's activations stay O(1): torch's default
+    `nn.Linear` initialisation (uniform +-1/sqrt(2048)) gives |logit| 0.2-0.4 on `trained_looking_batchnorm` networks, and an
+    ABSOLUTE logit bound checked only there says nothing about fp16 storage at |logit| 5-10.  scale 30 ->
+    |logit| up to ~5 (ResNet-50) / ~11 (ResNet-152, 12 channels) on tile-like input."""
+    model.fc.weight.data = model.fc.weight.data * float(scale)

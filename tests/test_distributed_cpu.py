@@ -131,3 +131,84 @@ def test_shards_partition_the_table():
         shards = [odd.shard(r, world) for r in range(world)]
         assert sum(len(s) for s in shards) == 4099 and max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
         assert np.array_equal(np.concatenate([s.theta_deg for s in shards]), odd.theta_deg)
+
+
+class _StubTiles(torch.utils.data.Dataset):
+    """Stands in for dataset.zind_data.ZindData in the un-fused N > 1 driver test: (x1, x2, is_match, fp0, fp1) examples."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, j):
+        g = torch.Generator().manual_seed(j)
+        return torch.randn(3, 4, 4, generator=g), torch.randn(3, 4, 4, generator=g), j % 2, f"/bev/x/0001/a_{j}.jpg", f"/bev/x/0001/b_{j}.jpg"
+
+
+class _StubVerifier(torch.nn.Module):
+    def forward(self, x1, x2, x3, x4, x5, x6):
+        return torch.stack([x1.mean((1, 2, 3)), x2.mean((1, 2, 3))], 1)
+
+
+def _unfused_worker(rank, world, port, n, bs, out_dir):
+    from types import SimpleNamespace
+
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from salve_amd import evaluate
+
+    loader, first_batch, counts = evaluate.sharded_loader(_StubTiles(n), bs, rank, world)
+    m = evaluate.run_test_epoch(SimpleNamespace(num_ce_classes=2), os.path.join(out_dir, f"preds_w{world}"), "", _StubVerifier().eval(), loader, "test",
+                                world=world, rank=rank, first_batch=first_batch, counts=counts)
+    torch.save(m, os.path.join(out_dir, f"u{world}_{rank}.pt"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,bs,world", [(38, 4, 2), (21, 8, 3), (6, 4, 3)])
+def test_unfused_test_epoch_on_several_ranks(tmp_path, n, bs, world):
+    """evaluate.run_test_epoch with world > 1 (gloo): the batches of the un-shuffled epoch are split into contiguous blocks of
+    WHOLE batches, every rank writes its own `batch_{i}.json` files under the batch's global index, one all-gather collects
+    (y_hat, y_true) for the metrics -- files and metrics identical to the single-process run (6 examples in batches of 4 over 3 ranks: one rank
+    has no batch and still takes part in the collective)."""
+    import json
+
+    _unfused_worker(0, 1, 0, n, bs, str(tmp_path))
+    mp.spawn(_unfused_worker, args=(world, _free_port(), n, bs, str(tmp_path)), nprocs=world, join=True)
+    one = sorted((tmp_path / "preds_w1").glob("batch_*.json"))
+    many = sorted((tmp_path / f"preds_w{world}").glob("batch_*.json"))
+    assert [f.name for f in one] == [f.name for f in many] and len(one) == -(-n // bs)
+    for a, b in zip(one, many):
+        assert json.load(open(a)) == json.load(open(b)), a.name
+    ref = torch.load(tmp_path / "u1_0.pt", weights_only=False)
+    for r in range(world):
+        assert torch.load(tmp_path / f"u{world}_{r}.pt", weights_only=False) == ref
+
+
+def test_render_pairs_deals_the_floor_list_round_robin(tmp_path, monkeypatch):
+    """render_dataset.render_pairs(rank, world): the reference's (building, floor) work list (scripts/render_dataset_bev.py:151-184:
+    buildings sorted, 1348 skipped) dealt round robin to the ranks -- disjoint, complete, in list order; no collective."""
+    from salve_amd import render_dataset as rd
+
+    monkeypatch.setitem(rd.DATASET_SPLITS, "tiny", ["0007", "0003", "1348", "0005"])
+    for bid, floors in (("0003", ["floor_01", "floor_02"]), ("0005", ["floor_01"]), ("0007", ["floor_00", "floor_01", "floor_02"]), ("1348", ["floor_01"])):
+        for f in floors:
+            (tmp_path / "hyp" / bid / f).mkdir(parents=True)
+    whole = rd.floor_work_list(str(tmp_path / "hyp"), "tiny", None)
+    assert whole == [("0003", "floor_01"), ("0003", "floor_02"), ("0005", "floor_01"), ("0007", "floor_00"), ("0007", "floor_01"), ("0007", "floor_02")]
+    seen = []
+    monkeypatch.setattr(rd, "render_building_floor_pairs", lambda *a, **k: seen.append((a[4], a[5])) or 2)
+    per_rank = []
+    for r in range(4):
+        seen.clear()
+        assert rd.render_pairs(1, "d", "b", "raw", str(tmp_path / "hyp"), None, ["rgb_texture"], "tiny", None, rank=r, world=4) == 2 * len(seen)
+        per_rank.append(list(seen))
+    assert per_rank == [whole[0::4], whole[1::4], whole[2::4], whole[3::4]]
+    assert sorted(sum(per_rank, [])) == sorted(whole)
+    with pytest.raises(ValueError):
+        rd.render_pairs(1, "d", "b", "raw", str(tmp_path / "hyp"), None, ["rgb_texture"], "tiny", "0003")
+    with pytest.raises(ValueError):
+        rd.render_pairs(1, "d", "b", "raw", str(tmp_path / "hyp"), None, ["rgb_texture"], "tiny", None, rank=4, world=4)

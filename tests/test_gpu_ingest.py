@@ -231,3 +231,80 @@ def test_hypotheses_without_points_in_the_window_are_dropped(tmp_path):
     assert len(far_names) == 2
     kept = sum((g["fp0"] for g in got), [])
     assert len(kept) == 4 and not any(u in n for n in kept for u in far_names)
+
+
+def _synthetic_pose_graph(pano_ids, seed=5):
+    """A floor's rooms and W/D/O objects, in the attributes layout.layout_pair_specs reads (salve/common/posegraph2d.py nodes,
+    salve/common/wdo.py:47-50)."""
+    rng = np.random.default_rng(seed)
+    wdo = lambda t, a, b: SimpleNamespace(type=t, vertices_local_2d=np.array([a, b], dtype=np.float64))
+    nodes = {}
+    for pid in pano_ids:
+        n = int(rng.integers(4, 9))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        rad = rng.uniform(0.8, 2.6, n)
+        room = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1)
+        objs = {"doors": [], "windows": [], "openings": []}
+        for j in range(int(rng.integers(1, 5))):
+            a = int(rng.integers(0, n))
+            p, q = room[a], room[(a + 1) % n]
+            t0, t1 = np.sort(rng.uniform(0, 1, 2))
+            kind = ("doors", "windows", "openings")[j % 3]
+            objs[kind].append(wdo(kind, p + t0 * (q - p), p + t1 * (q - p)))
+        nodes[int(pid)] = SimpleNamespace(room_vertices_local_2d=room, **objs)
+    return SimpleNamespace(nodes=nodes)
+
+
+@pytest.mark.parametrize("modalities", [["layout"], ["ceiling_rgb_texture", "floor_rgb_texture", "layout"]])
+def test_fused_layout_modalities_equal_the_unfused_route(tmp_path, modalities):
+    """The rasterised-layout modality through the FUSED pipeline (early_fusion.py:24-32, 59-60; rasteriser
+    bev_rendering_utils.py:48-156): per hypothesis, salve_layout_rasterise of pano i1's posed layout -> salve_bev_tile_pairs into
+    the channels behind the texture maps' -> the 6- / 18-channel stem.  Against the un-fused route -- the facade's
+    rasterize_room_layout_pair / render_bev_pair images, the reference's val transform, `model(x1 .. x6)` in the dataset's order
+    (zind_data.py:26, 110: ceiling 1, 2, floor 1, 2, layout 1, 2, each pair in FILE-NAME order) -- the logits must agree to the
+    last bit.  The partial-room numbers run against the pano ids, so the file-name order differs from (i1, i2) for some pairs."""
+    from salve_amd import layout, train_utils
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from salve_amd.pipeline import RenderVerifyPipeline
+    from salve_amd.utils import bev_rendering_utils as bru
+    from tests.test_gpu_dataset import config
+
+    raw, depth_root, hyp_root, fpaths = make_floor(tmp_path, reverse_rooms=True)
+    torch.manual_seed(4)
+    model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=modalities)).eval()
+    dev = torch.device(DEV)
+    hyps = ingest.load_floor_hypotheses(str(hyp_root), "0003", "floor_01")
+    img_fpaths = ingest.floor_pano_fpaths(str(raw), "0003")
+    swap = hyps.swap(img_fpaths)
+    assert swap.any() and not swap.all()
+    store = ingest.PanoStore(dev).load(img_fpaths, str(depth_root), "0003", np.concatenate([hyps.i1, hyps.i2]))
+    pano_ids = [pid for pid, _ in sorted(store.index.items(), key=lambda kv: kv[1])]
+    graph = _synthetic_pose_graph(pano_ids)
+    table = hyps.table(store, img_fpaths)
+    pipe = RenderVerifyPipeline(model, dev, chunk=4)     # 6 hypotheses: two chunks, the second partly filled
+    pipe.set_panos(store.rgb, store.depth)
+    with pytest.raises(RuntimeError, match="layout"):
+        pipe.prepare(table)
+    prepared = pipe.prepare(table, layouts=layout.FusedLayouts.from_pose_graph(table, pano_ids, graph, hyps.s))
+    fused = pipe.score(prepared).cpu()
+    assert pipe.valid_mask(prepared).all()
+    pipe.check("fused layout")
+
+    tf = train_utils.get_val_test_transform(config(str(tmp_path / "bev"), modalities))
+    for j in range(len(hyps)):
+        i1, i2 = int(hyps.i1[j]), int(hyps.i2[j])
+        S = Sim2.from_json(hyps.fpaths[j])
+        order = (lambda a, b: (b, a)) if swap[j] else (lambda a, b: (a, b))
+        imgs = []
+        if "floor_rgb_texture" in modalities:
+            for surface, zr in (("ceiling", [0.5, float("inf")]), ("floor", [-float("inf"), -1.0])):
+                a = SimpleNamespace(img_i1=img_fpaths[i1], img_i2=img_fpaths[i2],
+                                    depth_i1=str(depth_root / "0003" / f"{Path(img_fpaths[i1]).stem}.depth.png"),
+                                    depth_i2=str(depth_root / "0003" / f"{Path(img_fpaths[i2]).stem}.depth.png"),
+                                    scale=0.001, crop_ratio=80 / 512, crop_z_range=zr)
+                imgs += order(*bru.render_bev_pair(a, "0003", "floor_01", i1, i2, S, False))
+        imgs += order(*bru.rasterize_room_layout_pair(S, graph, "0003", "floor_01", i1, i2))
+        x = [t[None] for t in tf(*imgs)] + [None] * (6 - len(imgs))
+        with torch.no_grad():
+            unfused = model.cuda()(*x).cpu()[0]
+        assert torch.equal(unfused, fused[j]), (modalities, j, unfused, fused[j])
