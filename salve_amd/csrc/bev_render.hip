@@ -118,6 +118,7 @@ struct RasterEmit {
     int flip;       // H - 1 to flip vertically (np.flipud), -1: no flip
     int lane, nlanes;  // rows lane, lane + nlanes, ... of the bounding box (several lanes may share one triangle)
     bool skip;
+    int32_t* status;   // device status word: a vertex outside the image is REPORTED and the triangle left out (fence, below)
     // pixel (x, y) of the output image as a 32-bit element index (the image is smaller than 2048 x 2048; a 64-bit index product is
     // a quarter-rate v_mad_u64_u32 per access)
     __device__ __forceinline__ uint32_t pix(int x, int y) const { return (uint32_t)(((flip >= 0 ? flip - y : y) * W) + x); }
@@ -159,6 +160,14 @@ struct RasterEmit {
         if (area <= 1 || skip) return;
         int x0 = min(ax, min(bx, cx)), x1 = max(ax, max(bx, cx));
         const int y0 = min(ay, min(by, cy)), y1 = max(ay, max(by, cy));
+        // Fence: the rows and words below are addressed from the vertices without further tests, so a walk that
+        // handed over anything but three sites of THIS image -- the SLP-vectorised build of the general walk did, DESIGN.md section 8 --
+        // would read and write outside the render's buffers.  Such a triangle is left out and the render reported as failed: a wrong
+        // image that names itself instead of a memory fault.  (Three vector instructions per triangle of the general walk.)
+        if ((x0 | y0) < 0 || x1 >= W || y1 >= H) {
+            if (status && lane == 0) atomicOr(status, SALVE_STATUS_WALK_FAILED);
+            return;
+        }
         uint32_t ca = 0, cb = 0, cc = 0;
         bool have = false;
         const bool wide = (x1 - x0) > 40;
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     //          in place.   F: all lanes rasterise the queued triangles.
     if (!degenerate && !(dbg_flags & 1)) {
         SdGrid g = {H, W, wpr, occ, rmin, rmax, 0, 1, (dbg_flags & 32) ? nullptr : &d_star_table.off[0][0][0], scal[1], scal[2], scal[12], scal[13], (H <= 1024 && W <= 1024 && !(dbg_flags & 256)) ? tri_cache : nullptr};
-        RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (dbg_flags & 2) != 0};
+        RasterEmit raster = {H, W, wpr, occ, msk, bev, flip, 0, 1, (dbg_flags & 2) != 0, status};
         QueueEmit qemit = {triq, &scal[8], H * W, (dbg_flags & 1024) != 0, status};
         const int hard_cap = (H * W) >> 1;   // entries of two words: the site, and where its lean walk stood
         SdLean st;

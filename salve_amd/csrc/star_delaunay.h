@@ -449,6 +449,9 @@ SD_FN void sd_share_best(const SdGrid& g, const SdEdge& e, SdBest* best, int* sh
             const float ol = __uint_as_float((unsigned)sd_group_read(g, (int)__float_as_uint(best->lam), l));
             if (sd_beats(e, w, ox, oy, ol)) { w.px = ox; w.py = oy; w.lam = ol; }
         }
+        // (`changed` is never empty here, and the minimum's own lane is a contender in exact arithmetic; should the float thinning
+        //  ever drop every lane -- a NaN lambda would --, the candidate shared so far stays instead of an apex of (-1, -1))
+        if (w.px < 0) return;
         sd_best_set(*best, e, w.px, w.py, w.lam);
         *shared_x = w.px;
         *shared_y = w.py;

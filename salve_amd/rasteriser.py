@@ -125,16 +125,24 @@ class BevRasteriser:
             _lib.check(-1, "salve_bev_workspace_bytes")
         ws = self._ws_slots.get(self.ws_slot)
         if ws is None or ws.numel() < need:
+            if ws is not None:
+                # growing a slot: launches issued earlier -- possibly on OTHER streams (the pipeline runs scatter and densify on
+                # their own) -- may still read the old buffer, and the caching allocator hands its memory out again as soon as
+                # the last reference goes, ordered against the CURRENT stream only.  Growth is rare (a larger batch than any
+                # before): wait for the device.
+                torch.cuda.synchronize(self.device)
             ws = self._ws_slots[self.ws_slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ws
 
     def pano_index(self, pano_depth: torch.Tensor) -> torch.Tensor:
         """The pose-independent panorama index of these depth maps (include/salve_hip.h: salve_bev_pano_index_build), built
         on first use on the current stream and kept with the tensor OBJECT: it lives as long as the tensor does, a slice or a
-        copy builds its own, and a caller that overwrites the depth maps in place calls `drop_pano_index` first."""
+        copy builds its own.  The key includes the tensor's VERSION counter (torch bumps it on every in-place write: `copy_`,
+        `[...] =`, `add_` ...), so depth maps overwritten in place get a fresh index instead of silently rendering with the stale
+        one; only writes torch cannot see (a kernel given the raw pointer) need `drop_pano_index`."""
         idx = getattr(pano_depth, "_salve_pano_index", None)
         P = int(pano_depth.shape[0])
-        if idx is not None and idx[1] == (pano_depth.data_ptr(), P):
+        if idx is not None and idx[1] == (pano_depth.data_ptr(), P, pano_depth._version):
             return idx[0]
         assert pano_depth.is_contiguous() and tuple(pano_depth.shape[1:]) == self.pano_hw and pano_depth.element_size() == 2
         nbytes = self.lib.salve_bev_pano_index_bytes(ctypes.byref(self.cfg), P)
@@ -145,7 +153,7 @@ class BevRasteriser:
             st = self.lib.salve_bev_pano_index_build(ctypes.byref(self.cfg), ctypes.c_void_p(pano_depth.data_ptr()), P,
                                                      ctypes.c_void_p(self.sphere.data_ptr()), ctypes.c_void_p(buf.data_ptr()), nbytes, self._stream())
         _lib.check(st, "salve_bev_pano_index_build")
-        pano_depth._salve_pano_index = (buf, (pano_depth.data_ptr(), P))
+        pano_depth._salve_pano_index = (buf, (pano_depth.data_ptr(), P, pano_depth._version))
         return buf
 
     @staticmethod

@@ -41,3 +41,30 @@ def load_testhelp():
     lib.salve_debug_burn.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     lib.salve_debug_burn.restype = ctypes.c_int
     return lib
+
+
+def wide_golden_cases(golden_dir):
+    """tests/golden/g6_render_wide.npz (round 5): twelve full-size renders by the IMPORTED reference -- 2 on the cluttered scene,
+    2 of render_bev_image on the 2048 x 1024 cloud, 8 more box-room hypotheses.  Yields (case index, meta, bev, sparse), meta =
+    dict(kind, scene, H, W, pano, hyp, surface)."""
+    import numpy as np
+
+    g = np.load(golden_dir / "g6_render_wide.npz")
+    for ci in range(int(g["n_cases"][0])):
+        kind, scene, H, W, pi, hi, surf = (int(v) for v in g[f"c{ci}_meta"])
+        meta = dict(kind=("pair", "image")[kind], scene=("box", "cluttered")[scene], H=H, W=W, pano=pi, hyp=hi, surface=("floor", "ceiling")[surf],
+                    npts=int(g[f"c{ci}_npts"][0]))
+        yield ci, meta, g[f"c{ci}_bev"], g[f"c{ci}_sparse"]
+
+
+def oracle_wide_render(meta, mode):
+    """The oracle's render of one g6 case: panorama -> back-projection -> pose (hypothesis `hyp` of make_hypotheses(16, 1, 0)) ->
+    render_bev_image in `mode`."""
+    from oracle import bev_oracle as bo
+    from salve_amd import synthetic as syn
+
+    hyp = syn.make_hypotheses(16, 1, seed=0)
+    rgb, depth = syn.make_pano(meta["pano"], meta["H"], meta["W"], scene=meta["scene"])
+    a = bo.xyzrgb_from_arrays(depth, rgb, bo.floor_ceiling_z_range(meta["surface"]))
+    a, _ = bo.pose_pair(a, a[:1], hyp.R[meta["hyp"]], hyp.t[meta["hyp"]])
+    return bo.render_bev_image(a, mode=mode)

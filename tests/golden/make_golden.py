@@ -222,6 +222,67 @@ def main():
         print(f.name, f.stat().st_size)
 
 
+def main_r5():
+    """Round 5 (missing 4 / next 5): a wider reference-pinned sample for Tier C and config 5's geometry ->
+    g6_render_wide.npz.  Twelve more full-size renders by the IMPORTED reference: 2 on the cluttered scene, 2 of `render_bev_image`
+    on the 2048 x 1024 cloud (floor, ceiling), 8 more box-room hypotheses; per case the final image (`bev`, what render_bev_image
+    returns) and the sparse image (`sparse`, unflipped), plus the point count.  The existing files are not touched.
+    get_xyzrgb_from_depth hard-codes 1024 x 512 (bev_rendering_utils.py:373-374), so the 2048 x 1024 cloud comes from the oracle's
+    back-projection (pinned at 1024 x 512 against the reference by g4_render_full: xyzrgb sha) and everything from the pose onwards
+    is the reference -- the oracle SURVEY section 8d names for this size."""
+    install_stubs()
+    import salve.utils.zorder_utils as ref_zorder
+    import salve.utils.interpolation_utils as ref_interp
+    import salve.utils.bev_rendering_utils as ref_bev
+    import salve.utils.rotation_utils as ref_rot
+    from salve.common.bevparams import BEVParams
+    from salve.common.sim2 import Sim2
+
+    from oracle import bev_oracle as bo
+    from salve_amd import synthetic
+
+    hyp = synthetic.make_hypotheses(16, 1, seed=0)
+    bp = BEVParams()
+    Rm = ref_rot.rotmat2d(-90)
+    # (kind, scene, pano HxW, pano index, hypothesis, surface)
+    cases = [("pair", "cluttered", (512, 1024), 0, 2, "floor"), ("pair", "cluttered", (512, 1024), 1, 3, "ceiling"),
+             ("image", "box", (1024, 2048), 0, 4, "floor"), ("image", "box", (1024, 2048), 0, 5, "ceiling")]
+    cases += [("pair", "box", (512, 1024), k % 2, 6 + k, "floor" if k % 2 == 0 else "ceiling") for k in range(8)]
+    g = {"n_cases": np.array([len(cases)])}
+    for ci, (kind, scene, (H, W), pi, hi, surface) in enumerate(cases):
+        rgb, depth = synthetic.make_pano(pi, H, W, scene=scene)
+        zr = [-float("inf"), -1.0] if surface == "floor" else [0.5, float("inf")]
+        S = Sim2(R=hyp.R[hi].astype(np.float64), t=hyp.t[hi].astype(np.float64), s=1.0)
+        if kind == "pair":
+            _IMAGES["q.jpg"], _IMAGES["q.depth.png"] = rgb, depth
+            args = SimpleNamespace(img_i1="q.jpg", img_i2="q.jpg", depth_i1="q.depth.png", depth_i2="q.depth.png", scale=0.001,
+                                   crop_ratio=80 / 512, crop_z_range=zr)
+            xyzrgb = quiet(ref_bev.get_xyzrgb_from_depth, args, args.depth_i1, args.img_i1, False)
+        else:
+            xyzrgb = bo.xyzrgb_from_arrays(depth, rgb, bo.floor_ceiling_z_range(surface), crop_ratio=80 / 512)
+        xyzrgb[:, :2] = xyzrgb[:, :2] @ Rm.T                                             # bev_rendering_utils.py:443-446
+        xyzrgb[:, :2] = (xyzrgb[:, :2] @ S.rotation.T) + (S.translation * 1.5)           # :447-451
+        final = quiet(ref_bev.render_bev_image, bp, xyzrgb.copy(), False)
+        assert final is not None
+        # the sparse image, by the reference's own pieces in render_bev_image's order (:274-308)
+        xyz, rgbv = ref_bev.prune_to_2d_bbox(xyzrgb[:, :3], xyzrgb[:, 3:] * 255, bp.xlims[0], bp.ylims[0], bp.xlims[1], bp.ylims[1])
+        img_xy = np.round(bp.bevimg_Sim2_world.transform_from(xyz[:, :2])).astype(np.int64)
+        valid = ref_zorder.choose_elevated_repeated_vals(img_xy[:, 0], img_xy[:, 1], xyz[:, 2])
+        sparse = np.zeros((501, 501, 3), dtype=np.uint8)
+        sparse[img_xy[valid][:, 1], img_xy[valid][:, 0]] = rgbv[valid]
+        if ci in (0, 2):   # the pieces ARE render_bev_image: checked on one case per geometry (the interpolation takes seconds)
+            interp_img = ref_interp.interp_dense_grid_from_sparse(np.zeros((501, 501, 3), dtype=np.uint8), img_xy[valid], rgbv[valid],
+                                                                  grid_h=501, grid_w=501, is_semantics=False)
+            assert np.array_equal(np.flipud(ref_interp.remove_hallucinated_content(sparse, interp_img)), final)
+        g[f"c{ci}_meta"] = np.array([0 if kind == "pair" else 1, 0 if scene == "box" else 1, H, W, pi, hi, 0 if surface == "floor" else 1])
+        g[f"c{ci}_npts"] = np.array([img_xy.shape[0]])
+        g[f"c{ci}_bev"] = final
+        g[f"c{ci}_sparse"] = sparse
+        print(ci, kind, scene, (H, W), pi, hi, surface, img_xy.shape[0], int(valid.sum()), flush=True)
+    np.savez_compressed(OUT / "g6_render_wide.npz", **g)
+    print("g6_render_wide.npz", (OUT / "g6_render_wide.npz").stat().st_size)
+
+
 def make_zind_partition() -> None:
     """The official ZInD train/val/test building split (public data, https://github.com/zillow/zind zind_partition.json)
     as the reference carries it (salve/dataset/zind_partition.py) -> salve_amd/dataset/zind_partition.json.
@@ -237,5 +298,8 @@ def make_zind_partition() -> None:
 
 
 if __name__ == "__main__":
-    main()
-    make_zind_partition()
+    if "--r5" in sys.argv:     # round 5's additional file only; the files of rounds 1-4 stay byte for byte what they were
+        main_r5()
+    else:
+        main()
+        make_zind_partition()

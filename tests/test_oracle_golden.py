@@ -125,3 +125,17 @@ def test_exact_mode_vs_reference_tiers(full_cases, ci):
     sub = slice(0, 4000)  # brute-force check is O(T*n): bound it
     assert bo.check_delaunay_windowed(sp, e1["tri"][sub])
     assert bo.check_delaunay_windowed(sp, bo.ccw(sp, Delaunay(sp.astype(float)).simplices)[sub])
+
+
+@pytest.mark.parametrize("ci", list(range(12)))
+def test_g6_wide_sample_scipy_mode_is_the_reference(golden_dir, ci):
+    """Round 5's wider reference-pinned sample (tests/golden/g6_render_wide.npz, made by importing the reference): 2 renders of the
+    cluttered scene, 2 of render_bev_image on the 2048 x 1024 cloud (BASELINE config 5's geometry), 8 more box-room hypotheses.  The
+    oracle in scipy mode reproduces the reference's sparse and final images bit for bit, and its in-window point count."""
+    from _helpers import oracle_wide_render, wide_golden_cases
+
+    _, meta, bev, sparse = list(wide_golden_cases(golden_dir))[ci]
+    r = oracle_wide_render(meta, "scipy")
+    assert r["img_xy"].shape[0] == meta["npts"]
+    assert np.array_equal(r["sparse"], sparse), meta
+    assert np.array_equal(r["bev"], bev), meta

@@ -126,3 +126,26 @@ def test_tier_c_report_exact_mode_vs_reference_output(tier_c_cases):
     spread = float((torch.cat(logits) - logits[0]).abs().max())
     print(f"logit spread across the three hypotheses {spread:.2e}")
     assert spread > 1e-3
+
+
+def test_tier_c_report_on_the_wide_sample(golden_dir):
+    """Tier C over round 5's wider reference-pinned sample (g6_render_wide.npz: 2 cluttered-scene renders, 2 at config 5's
+    2048 x 1024 geometry, 8 more box-room hypotheses -- with the three cases above 18 full-size renders on two scenes and two
+    geometries).  The canonical (exact) mode against the reference's own, input-order-dependent image: sparse image bit for bit
+    (Tier A), the same ceilings as above on the share of differing pixels and their mean (12 % of the covered pixels, 2.5 grey
+    levels).  The LARGEST single-pixel difference is reported, not bounded: the wider sample holds a pixel at 194 grey levels (box
+    room, ceiling, hypothesis 7) where the three cases above stop at 89 -- a pixel inside a co-circular configuration takes the
+    colour mix of whichever of the equally valid triangles encloses it, and on a noise texture two such mixes can be far apart."""
+    from _helpers import oracle_wide_render, wide_golden_cases
+
+    worst = [0.0, 0.0, 0]
+    for ci, meta, bev, sparse in wide_golden_cases(golden_dir):
+        e = oracle_wide_render(meta, "exact")
+        assert np.array_equal(e["sparse"], sparse), meta
+        d = np.abs(e["bev"].astype(int) - bev.astype(int)).max(-1)
+        covered = e["bev"].any(-1) | bev.any(-1)
+        frac, mean, mx = (d > 0).sum() / covered.sum(), d[covered].mean(), int(d.max())
+        print(f"case {ci} ({meta['scene']}, {meta['W']}x{meta['H']}, {meta['surface']}): Tier-C pixel fraction {frac:.4f}, mean diff {mean:.3f}, max diff {mx}")
+        assert frac <= 0.12 and mean <= 2.5, meta
+        worst = [max(worst[0], frac), max(worst[1], mean), max(worst[2], mx)]
+    print(f"wide sample, worst case: {100 * worst[0]:.1f} % of the covered pixels, mean {worst[1]:.2f}, max {worst[2]} grey levels")

@@ -116,7 +116,7 @@ def main():
             "pooling from the last block's fp32 sums gains 6-20 %, an fp32 residual stream -- which would double the block outputs' bytes -- a factor of two on",
             "ResNet-50 and nothing on ResNet-152.  It is the price of a 16-bit storage type with 11 significand bits (bf16: 6-8 x worse), not of one rounding point.",
             "What the reference's consumers read are the softmax PROBABILITIES (`y_hat_probs`, scripts/test.py:217-229, 52-81): with two classes",
-            "|dp| = p (1 - p) |d(z1 - z0)| <= e^-|z1 - z0| x 2 rel |z|, which peaks near |z1 - z0| = 1 at ~ rel: the probabilities stay within 2e-4 ... 5e-4 at ANY logit",
+            "|dp| = p (1 - p) |d(z1 - z0)| <= e^-|z1 - z0| x 2 rel |z|, which peaks near |z1 - z0| = 1 at ~ rel: the probabilities stay within 2e-4 at ANY logit",
             "magnitude (last column).  Contract (DESIGN.md section 2, tests/test_gpu_verifier.py::test_logits_at_realistic_magnitude): |logit error| <= 1e-3 x max(1, max |logit|),",
             "probabilities within 1e-3 absolute.  bf16 storage misses even that on ResNet-152 -- the kernels store fp16."]
     if "--out" in sys.argv:
