@@ -60,6 +60,16 @@ def counted_traffic(key: str, field: str = "bytes_per_unit"):
         return None, None
 
 
+def counted_issue(key: str):
+    """The densify kernel's instruction-issue counters at the launch shape `key` names (profiles/traffic.json, written by the SQ pass
+    of the profile refresh): the rasteriser's dominant kernel is bound by vector-instruction issue, not by HBM, so
+    the line carries that bound beside the contractual HBM fraction.  None where the file has no entry."""
+    try:
+        return json.loads(TRAFFIC_FILE.read_text())[key]
+    except Exception:
+        return None
+
+
 def _cores() -> int:
     """Physical cores this process may use (the box's share), for the CPU baseline."""
     try:
@@ -262,6 +272,7 @@ def main() -> None:
         ras_traffic_raw, _ = counted_traffic(f"rasteriser/{pano_w}x{pano_h}/launch{renders}", "bytes_per_unit_raw_fetch")
         ver_traffic, ver_src = counted_traffic(f"verifier/resnet{args.layers}-{6 * S}ch/launch{full_n}")
         ver_alg, _ = counted_traffic(f"verifier_algorithmic/resnet{args.layers}-{6 * S}ch")
+        issue = counted_issue(f"densify_issue/{pano_w}x{pano_h}/launch{renders}")
         config5 = (pano_h, pano_w, S, args.layers) == (1024, 2048, 2, 152)
         out = {
             "metric": "alignment hypotheses/sec (render+verify)", "value": round(value, 2), "unit": "hypotheses/s",
@@ -281,7 +292,13 @@ def main() -> None:
                          "traffic": None if ras_traffic is None else int(ras_traffic * renders),
                          "traffic_raw_fetch": None if ras_traffic_raw is None else int(ras_traffic_raw * renders), "traffic_source": ras_src,
                          "launch_ms": round(ras_ms, 3), "scatter_ms": round(scat_ms, 3), "densify_ms": round(dens_ms, 3),
-                         "launches_timed": len(vfull), "renders_per_launch": renders, "algorithmic_bytes_per_render": bpr},
+                         "launches_timed": len(vfull), "renders_per_launch": renders, "algorithmic_bytes_per_render": bpr,
+                         # the bound that BINDS the dominant kernel (bev_densify_kernel): VALU busy share of the SIMD cycles and vector /
+                         # scalar wave-instructions per render, from the SQ counter pass at this launch shape (null: no pass at this shape)
+                         "valu_busy": None if issue is None else issue.get("valu_busy"),
+                         "vector_insts_per_render": None if issue is None else issue.get("vector_insts_per_render"),
+                         "scalar_insts_per_render": None if issue is None else issue.get("scalar_insts_per_render"),
+                         "issue_source": None if issue is None else issue.get("source")},
             # the verifier against BOTH of its roofs: the dense fp16 MFMA peak (frac) and the HBM time of its activation traffic at
             # the present fusion level (bound_hbm_ms = algorithmic activation + weight bytes / 6.3 TB/s achievable)
             "roofline_verifier": {"kernel": "stem_pool / bottleneck / conv kernels of one ResNet forward", "bound": "mfma",

@@ -169,7 +169,7 @@ class RenderVerifyPipeline:
             jobs2_slot.append(slot)
             jobs2_chan.append(6 * si + 3 * (1 - swap))
         # job tables are stored hypothesis-major so that a chunk is a contiguous slice
-        st = lambda parts: np.stack(parts, 1).reshape(-1)
+        st = lambda parts: np.stack(parts, 1).reshape(-1) if parts else np.zeros(0, dtype=np.int64)   # (layout only: no texture jobs)
         prepared = {
             "n": N,
             "i2": np.asarray(hyp.i2).astype(np.int64),
