@@ -187,7 +187,7 @@ def main() -> None:
     ap.add_argument("--pano-hw", default="512x1024", help="panorama HxW: 512x1024 (configs 1-4) | 1024x2048 (config 5)")
     ap.add_argument("--surfaces", default="floor", help="floor | ceiling | floor,ceiling (config 5: 12-channel early fusion)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the logits all-gather even with one rank")
-    ap.add_argument("--scene", default="box", help="synthetic scene: box (SURVEY 8d) | cluttered (occluding boxes + door opening)")
+    ap.add_argument("--scene", default="box", help="synthetic scene: box (SURVEY 8d) | cluttered (occluding boxes + door opening) | noisy (cluttered + network-like depth errors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -122,11 +122,34 @@ def make_cluttered_room_depth_mm(pano_idx: int, H: int = 512, W: int = 1024) -> 
     return np.clip(mm, 0, 65535).astype(np.uint16)
 
 
-SCENES = {"box": make_box_room_depth_mm, "cluttered": make_cluttered_room_depth_mm}
+def make_noisy_room_depth_mm(pano_idx: int, H: int = 512, W: int = 1024) -> np.ndarray:
+    """uint16 [H, W]: the cluttered scene seen through a depth NETWORK instead of a ray caster -- what the reference's renderer is
+    actually fed (HoHoNet predictions, salve/utils/infer_depth.py:55-62).  Two error terms on the exact depth: a smooth
+    multiplicative bias field (+-2.5 %: a few low-frequency sinusoids over the panorama -- planes that bend and tilt) and per-pixel
+    noise (sigma 0.6 %, i.e. ~1.5 cm at 2.5 m), plus a small fraction of outliers at depth discontinuities left to the z filter.
+    The floor / ceiling clouds of this scene are ragged: neighbouring panorama pixels no longer land on neighbouring BEV pixels in
+    order, rows interleave, holes and isolated sites appear inside the cloud -- more outline, more hard sites for the general star
+    walk than the box room or the cluttered scene (the headline is measured on the easiest input)."""
+    exact = make_cluttered_room_depth_mm(pano_idx, H, W).astype(np.float64)
+    rng = np.random.default_rng(seed=11_000_003 + pano_idx)
+    v, u = np.meshgrid(np.arange(H, dtype=np.float64) / H, np.arange(W, dtype=np.float64) / W, indexing="ij")
+    bias = np.zeros((H, W))
+    for _ in range(4):
+        fu, fv = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        bias += rng.uniform(0.004, 0.009) * np.sin(2 * np.pi * (fu * u + rng.uniform()) ) * np.cos(2 * np.pi * (fv * v + rng.uniform()))
+    noisy = exact * (1.0 + bias + rng.normal(0.0, 0.006, size=(H, W)))
+    # a network smears depth discontinuities: 1 % of the pixels take the mean of their own and their right neighbour's depth
+    smear = rng.random((H, W)) < 0.01
+    noisy = np.where(smear, 0.5 * (noisy + np.roll(noisy, -1, axis=1)), noisy)
+    return np.clip(np.round(noisy), 0, 65535).astype(np.uint16)
+
+
+SCENES = {"box": make_box_room_depth_mm, "cluttered": make_cluttered_room_depth_mm, "noisy": make_noisy_room_depth_mm}
 
 
 def make_pano(pano_idx: int, H: int = 512, W: int = 1024, scene: str = "box") -> Tuple[np.ndarray, np.ndarray]:
-    """(rgb uint8 [H,W,3], depth uint16 [H,W]).  scene: "box" (the benchmark's scene) or "cluttered"."""
+    """(rgb uint8 [H,W,3], depth uint16 [H,W]).  scene: "box" (the benchmark's scene), "cluttered" (occluders + a door)
+    or "noisy" (the cluttered scene with network-like depth errors)."""
     return make_pano_rgb(pano_idx, H, W), SCENES[scene](pano_idx, H, W)
 
 

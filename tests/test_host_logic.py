@@ -343,3 +343,15 @@ def test_render_order_sorts_by_panorama_inside_chunks_only():
             assert (np.diff(i1[blk]) >= 0).all()                         # ... in panorama order
             for p in np.unique(i1[blk]):                                 # ... stable: ties keep the table's order
                 assert (np.diff(blk[i1[blk] == p]) > 0).all()
+
+
+def test_noisy_scene_is_the_cluttered_scene_with_network_like_depth_errors():
+    """synthetic.make_pano(scene="noisy"): the cluttered scene's depth under a smooth bias field (a few %), per-pixel noise (sigma
+    0.6 %) and smeared discontinuities -- deterministic per index, same colours, errors of the size a depth network makes."""
+    clut = synthetic.make_cluttered_room_depth_mm(3, 128, 256).astype(np.float64)
+    noisy = synthetic.make_noisy_room_depth_mm(3, 128, 256).astype(np.float64)
+    assert np.array_equal(noisy, synthetic.make_noisy_room_depth_mm(3, 128, 256))
+    rel = (noisy - clut) / clut
+    assert 0.004 < np.std(rel) < 0.03 and np.abs(np.median(rel)) < 0.02
+    assert (np.abs(rel) < 0.05).mean() > 0.98          # the smeared discontinuities are the rest
+    assert np.array_equal(synthetic.make_pano(3, 64, 128, scene="noisy")[0], synthetic.make_pano(3, 64, 128)[0])
