@@ -355,3 +355,42 @@ def test_noisy_scene_is_the_cluttered_scene_with_network_like_depth_errors():
     assert 0.004 < np.std(rel) < 0.03 and np.abs(np.median(rel)) < 0.02
     assert (np.abs(rel) < 0.05).mean() > 0.98          # the smeared discontinuities are the rest
     assert np.array_equal(synthetic.make_pano(3, 64, 128, scene="noisy")[0], synthetic.make_pano(3, 64, 128)[0])
+
+
+def test_fused_layout_host_side():
+    """The host side of the fused layout modality (no GPU): the modality sets the pipeline accepts (early_fusion.py:24-32), the posed /
+    identity layout specs FusedLayouts builds from a pose graph -- pano i1's room and W/D/Os under i2Ti1 (bev_rendering_utils.py:82, 90),
+    every panorama's own layout closed like the reference closes it (:76-77), an empty image for a panorama the graph lacks -- and the
+    refusal to rasterise without a HIP device."""
+    from types import SimpleNamespace
+
+    from salve_amd import _lib, layout, pipeline
+    from salve_amd.common.sim2 import Sim2
+
+    assert pipeline.surfaces_for(["layout"]) == [] and pipeline.surfaces_for(["layout", "floor_rgb_texture", "ceiling_rgb_texture"]) == ["ceiling", "floor"]
+    with pytest.raises(RuntimeError):
+        pipeline.surfaces_for(["layout", "floor_rgb_texture"])
+    wdo = lambda t, a, b: SimpleNamespace(type=t, vertices_local_2d=np.array([a, b], dtype=np.float64))
+    node = lambda v, d, w, o: SimpleNamespace(room_vertices_local_2d=np.array(v, dtype=np.float64), doors=d, windows=w, openings=o)
+    graph = SimpleNamespace(nodes={4: node([[-1, -1], [1, -1], [1, 1], [-1, 1]], [wdo("doors", [1, -0.5], [1, 0.3])], [], []),
+                                   7: node([[-2, -1], [1, -1], [1, 1]], [], [wdo("windows", [0, -1], [0.5, -1])], [wdo("openings", [1, 0], [1, 0.5])])})
+    table = synthetic.make_hypotheses(5, 3, seed=1)
+    table.i1[:] = [0, 1, 0, 1, 0]
+    table.i2[:] = [1, 0, 1, 0, 1]
+    pano_ids = [4, 7, 9]                         # store index -> pano id; pano 9 is not in the graph (no hypothesis names it)
+    fl = layout.FusedLayouts.from_pose_graph(table, pano_ids, graph)
+    assert len(fl.posed) == 5 and len(fl.identity) == 3
+    for j in range(5):
+        S = Sim2(table.R[j], table.t[j], 1.0)
+        n1 = graph.nodes[pano_ids[int(table.i1[j])]]
+        room, wdos = fl.posed[j]
+        closed = np.vstack([n1.room_vertices_local_2d, n1.room_vertices_local_2d[:1]])
+        assert np.array_equal(room, S.transform_from(closed))
+        objs = list(n1.doors) + list(n1.windows) + list(n1.openings)
+        assert [w[0] for w in wdos] == [o.type for o in objs]
+        assert all(np.array_equal(w[1], S.transform_from(o.vertices_local_2d)) for w, o in zip(wdos, objs))
+    room7, wdos7 = fl.identity[1]
+    assert room7.shape == (4, 2) and np.array_equal(room7[0], room7[-1]) and [w[0] for w in wdos7] == ["windows", "openings"]
+    assert fl.identity[2][0].shape == (0, 2) and fl.identity[2][1] == []
+    with pytest.raises(_lib.SalveHipError):
+        layout.pack_layouts(fl.posed, "cpu")
