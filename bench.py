@@ -70,6 +70,48 @@ def counted_issue(key: str):
         return None
 
 
+def power_probe(fn, seconds: float = 3.0, device_index: int = 0):
+    """Board power and shader clock while `fn` (one verifier forward) runs in a sustained loop, OUTSIDE the timed region: the forward runs
+    at the board's power limit, so the clock the matrix pipes actually get -- not the 2.4 GHz the 2.5 PFLOP/s peak
+    assumes -- is part of what the roofline fraction means.  rocm-smi is asked from a thread while the loop runs; None where it is not
+    available or says nothing."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        time.sleep(1.0)   # let the clocks settle under load
+        while not stop.is_set():
+            try:
+                out = subprocess.run([exe, "-d", str(device_index), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                pw = re.search(r"Graphics Package Power \(W\):\s*([0-9.]+)", out)
+                ck = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", out)
+                if pw and ck:
+                    samples.append((float(pw.group(1)), float(ck.group(1))))
+            except Exception:
+                return
+            time.sleep(0.3)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=15)
+    if not samples:
+        return None
+    return {"power_w": round(float(np.mean([a for a, _ in samples])), 1), "sclk_mhz": round(float(np.mean([b for _, b in samples])), 1), "samples": len(samples)}
+
+
 def _cores() -> int:
     """Physical cores this process may use (the box's share), for the CPU baseline."""
     try:
@@ -189,6 +231,7 @@ def main() -> None:
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the logits all-gather even with one rank")
     ap.add_argument("--scene", default="box", help="synthetic scene: box (SURVEY 8d) | cluttered (occluding boxes + door opening) | noisy (cluttered + network-like depth errors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the 3 s loop of verifier forwards under rocm-smi (board power, shader clock)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -309,6 +352,13 @@ def main() -> None:
                                   "bound_hbm_ms": None if ver_alg is None else round(ver_alg * full_n / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3, 3),
                                   "traffic": None if ver_traffic is None else int(ver_traffic * full_n), "traffic_source": ver_src},
         }
+        if world == 1 and not args.no_power_probe:
+            # the verifier forward in a sustained loop under rocm-smi (outside the timed region): power and the clock it leaves
+            probe = power_probe(lambda: pipe.engine.forward_nhwc(pipe.tile_bufs[0][:full_n], out=logits[:full_n]), device_index=local_rank)
+            if probe is not None:
+                out["roofline_verifier"].update({"power_w": probe["power_w"], "sclk_mhz": probe["sclk_mhz"], "power_samples": probe["samples"],
+                                                 "peak_at_sclk": round(MFMA_PEAK_TFLOPS * probe["sclk_mhz"] / 2400.0, 1),
+                                                 "frac_at_sclk": round(tflops / (MFMA_PEAK_TFLOPS * probe["sclk_mhz"] / 2400.0), 5)})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
