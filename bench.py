@@ -70,18 +70,37 @@ def counted_issue(key: str):
         return None
 
 
+def _hwmon_of(device_index: int):
+    """The sysfs hwmon directory (power1_input in microwatts, freq1_input in Hz) of the GPU torch calls cuda:<device_index>, matched by
+    PCI address; None if sysfs does not show it."""
+    import glob
+
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:
+        return None
+    for dev in glob.glob("/sys/class/drm/card*/device"):
+        try:
+            if os.path.basename(os.path.realpath(dev)) != want:
+                continue
+            for h in glob.glob(dev + "/hwmon/hwmon*"):
+                if os.path.exists(h + "/power1_input") and os.path.exists(h + "/freq1_input"):
+                    return h
+        except OSError:
+            continue
+    return None
+
+
 def power_probe(fn, seconds: float = 3.0, device_index: int = 0):
     """Board power and shader clock while `fn` (one verifier forward) runs in a sustained loop, OUTSIDE the timed region: the forward runs
     at the board's power limit, so the clock the matrix pipes actually get -- not the 2.4 GHz the 2.5 PFLOP/s peak
-    assumes -- is part of what the roofline fraction means.  rocm-smi is asked from a thread while the loop runs; None where it is not
-    available or says nothing."""
-    import re
-    import shutil
-    import subprocess
+    assumes -- is part of what the roofline fraction means.  Read from the GPU's hwmon files in sysfs by a thread while the loop runs (no
+    child process); None where sysfs does not show the device."""
     import threading
 
-    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(exe):
+    hw = _hwmon_of(device_index)
+    if hw is None:
         return None
     samples, stop = [], threading.Event()
 
@@ -89,14 +108,12 @@ def power_probe(fn, seconds: float = 3.0, device_index: int = 0):
         time.sleep(1.0)   # let the clocks settle under load
         while not stop.is_set():
             try:
-                out = subprocess.run([exe, "-d", str(device_index), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
-                pw = re.search(r"Graphics Package Power \(W\):\s*([0-9.]+)", out)
-                ck = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", out)
-                if pw and ck:
-                    samples.append((float(pw.group(1)), float(ck.group(1))))
+                pw = int(open(hw + "/power1_input").read()) / 1e6
+                ck = int(open(hw + "/freq1_input").read()) / 1e6
+                samples.append((pw, ck))
             except Exception:
                 return
-            time.sleep(0.3)
+            time.sleep(0.1)
 
     th = threading.Thread(target=sampler, daemon=True)
     th.start()
@@ -106,10 +123,15 @@ def power_probe(fn, seconds: float = 3.0, device_index: int = 0):
             fn()
         torch.cuda.synchronize()
     stop.set()
-    th.join(timeout=15)
+    th.join(timeout=5)
     if not samples:
         return None
-    return {"power_w": round(float(np.mean([a for a, _ in samples])), 1), "sclk_mhz": round(float(np.mean([b for _, b in samples])), 1), "samples": len(samples)}
+    try:
+        cap = int(open(hw + "/power1_cap").read()) / 1e6
+    except Exception:
+        cap = None
+    return {"power_w": round(float(np.mean([a for a, _ in samples])), 1), "sclk_mhz": round(float(np.mean([b for _, b in samples])), 1),
+            "power_cap_w": cap, "samples": len(samples)}
 
 
 def _cores() -> int:
@@ -231,7 +253,7 @@ def main() -> None:
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the logits all-gather even with one rank")
     ap.add_argument("--scene", default="box", help="synthetic scene: box (SURVEY 8d) | cluttered (occluding boxes + door opening) | noisy (cluttered + network-like depth errors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-power-probe", action="store_true", help="skip the 3 s loop of verifier forwards under rocm-smi (board power, shader clock)")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the 3 s loop of verifier forwards during which board power and shader clock are read from sysfs")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -353,10 +375,10 @@ def main() -> None:
                                   "traffic": None if ver_traffic is None else int(ver_traffic * full_n), "traffic_source": ver_src},
         }
         if world == 1 and not args.no_power_probe:
-            # the verifier forward in a sustained loop under rocm-smi (outside the timed region): power and the clock it leaves
+            # the verifier forward in a sustained loop (outside the timed region) while a thread reads the GPU's hwmon files: power and the clock it leaves
             probe = power_probe(lambda: pipe.engine.forward_nhwc(pipe.tile_bufs[0][:full_n], out=logits[:full_n]), device_index=local_rank)
             if probe is not None:
-                out["roofline_verifier"].update({"power_w": probe["power_w"], "sclk_mhz": probe["sclk_mhz"], "power_samples": probe["samples"],
+                out["roofline_verifier"].update({"power_w": probe["power_w"], "power_cap_w": probe["power_cap_w"], "sclk_mhz": probe["sclk_mhz"], "power_samples": probe["samples"],
                                                  "peak_at_sclk": round(MFMA_PEAK_TFLOPS * probe["sclk_mhz"] / 2400.0, 1),
                                                  "frac_at_sclk": round(tflops / (MFMA_PEAK_TFLOPS * probe["sclk_mhz"] / 2400.0), 5)})
         if world == 1 and not args.no_cpu_baseline:
