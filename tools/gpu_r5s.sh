@@ -18,9 +18,9 @@ step 300 bench_noisy.log python bench.py --steps 10 --warmup 3 --scene noisy --n
 step 400 bench_c5.log python bench.py --pano-hw 1024x2048 --surfaces floor,ceiling --layers 152 --hyps 1024 --panos 16 --chunk 512 --steps 5 --warmup 2 --no-cpu-baseline
 step 300 bench_rccl.log python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --force-dist --no-cpu-baseline
 cd /tmp
-step 300 prof1.log rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof1" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline
-step 300 prof3.log rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof3" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --streams 3
-step 300 prof5.log rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof5" -- python3 "$GRAFT_REPO_ROOT/bench.py" --pano-hw 1024x2048 --surfaces floor,ceiling --layers 152 --hyps 1024 --panos 16 --chunk 512 --steps 2 --warmup 1 --no-cpu-baseline
+step 300 prof1.log rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof1" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-power-probe
+step 300 prof3.log rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof3" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-power-probe --streams 3
+step 300 prof5.log rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof5" -- python3 "$GRAFT_REPO_ROOT/bench.py" --pano-hw 1024x2048 --surfaces floor,ceiling --layers 152 --hyps 1024 --panos 16 --chunk 512 --steps 2 --warmup 1 --no-cpu-baseline --no-power-probe
 R="$GRAFT_REPO_ROOT/tools/pmc_render.py"
 step 300 pmc_f.log rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $R 4096 64
 step 300 pmc_w.log rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $R 4096 64
