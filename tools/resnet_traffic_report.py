@@ -1,4 +1,4 @@
-"""Per-launch roofline table of one verifier forward from gpurun_out/r3traffic (tools/gpu_r3_traffic.sh).
+"""Per-launch roofline table of one verifier forward from gpurun_out/r3traffic (tools/archive/gpu_r3_traffic.sh).
 
 For every launch of the LAST of the three forwards: duration (kernel trace, no counters), algorithmic FLOP and bytes of the
 ops it executes (activations in + residual + out, fp16; weights once), the two roofline times (FLOP / 2.5 PFLOP/s dense fp16
