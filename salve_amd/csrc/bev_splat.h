@@ -30,11 +30,8 @@ constexpr int BLK_W = 16, BLK_H = 4;        // panorama block = one wavefront: l
 #define SPLAT_BATCH_N 4
 #endif
 constexpr int SPLAT_BATCH = SPLAT_BATCH_N;  // blocks a wavefront keeps in flight (loads of all of them issued before any is used)
-// Timing-only builds (tools/splat_ablation.sh; wrong images): SPLAT_ABL bit 0 = cull only (no point is processed),
-// bit 1 = no block loop at all, bit 2 = no emission (nothing is written), bit 3 = no LDS atomic, bit 4 = no loads (made-up depth / table values).
-#ifndef SPLAT_ABL
-#define SPLAT_ABL 0
-#endif
+// (The timing-only switches of this kernel -- cull only / no block loop / no emission / no LDS atomic / no loads -- are a patch,
+// tools/ablations/timing_switches.patch, applied by tools/splat_ablation.sh: the product source carries none.)
 
 // Block grid of a panorama: nbr block rows x (gpr groups of 64 block columns); entry (br, g, j) is block column 64 g + j.
 struct PanoGrid {
@@ -223,7 +220,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_
     int my_in_window = 0;
     __syncthreads();
 
-    for (; !(SPLAT_ABL & 2);) {
+    for (;;) {
         // a wavefront takes one group of 64 blocks at a time (dynamic: the groups that reach a tile are few and uneven)
         int g = 0;
         if (lane == 0) g = atomicAdd(&s.next_group, 1);
@@ -239,7 +236,6 @@ __global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_
             hit = hit && px + qx + slack >= wx0 && px - qx - slack <= wx1 && py + qy + slack >= wy0 && py - qy - slack <= wy1;
         }
         unsigned long long m = __ballot(hit);
-        if (SPLAT_ABL & 1) { my_in_window += (int)__popcll(m); continue; }
         if (m == 0ull) continue;
         const int br = g / pg.gpr, gc = g - br * pg.gpr;
         const int vr = br * BLK_H + (lane >> 4);                 // row of this lane's pixel in every block of the group
@@ -267,8 +263,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_
 #pragma unroll
             for (int k = 0; k < SPLAT_BATCH; k++) {
                 const uint32_t uu = ok[k] ? (uint32_t)u[k] : 0u;   // lanes without a pixel read pixel (v, 0): valid memory, result unused
-                if (SPLAT_ABL & 16) { dep[k] = 1500u + (uu & 255u); ctu[k] = 0.001 * (double)(uu & 511u); stu[k] = 0.3; }
-                else { dep[k] = dpano[vrow + uu]; ctu[k] = ct[uu]; stu[k] = st[uu]; }
+                dep[k] = dpano[vrow + uu]; ctu[k] = ct[uu]; stu[k] = st[uu];
             }
 #pragma unroll
             for (int k = 0; k < SPLAT_BATCH; k++) {
@@ -297,8 +292,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_
                 }
                 const double zs = floor(b.z) - c.zmin;   // unit slices from an integer z_min: exact (zorder_utils.py:49-59)
                 const bool splat = live && zs >= 0.0 && zs < (double)c.nslices && ix >= 0 && ix < c.W && iy >= 0 && iy < c.H;
-                if (SPLAT_ABL & 8) my_in_window += (int)zs + ix;
-                else if (splat)
+                if (splat)
                     atomicMax(&s.tile[(iy - ty0) * TILE_LD + (ix - tx0)], ((uint32_t)((int)zs + 1) << KEY_SLICE_SHIFT) | p);
             }
         }
@@ -307,7 +301,6 @@ __global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_
     if (lane == 0 && my_in_window) atomicAdd(&s.in_window, my_in_window);
     __syncthreads();
     if (tid == 0 && in_window && s.in_window) atomicAdd(in_window + rid, s.in_window);
-    if (SPLAT_ABL & 4) return;
     const uint8_t* colours = rgb + ((size_t)h.pano_idx * c.pano_h + c.crop_rows) * c.pano_w * 3;
     emit_tile<DEV>(c, s, colours, bev_all + (size_t)rid * c.H * c.W, bitmaps_all + (size_t)rid * 2 * ntiles * TILE_H * TILE_WORDS,
                    dbg_keys ? dbg_keys + (size_t)rid * c.H * c.W : nullptr, t, ntiles, tx0, ty0);

@@ -29,12 +29,8 @@ constexpr int C8_THREADS = 512;
 constexpr int C8_BM = 256, C8_BN = 256, C8_KS = 64;
 constexpr int C8_HALF_E = 128 * C8_KS;   // uint16 elements of a half-tile
 
-// development ablations (timing only)
-#if defined(C8_NO_MFMA)
-#define C8_MFMA(B_, A_, C_) { asm volatile("" ::"v"(B_), "v"(A_)); }
-#else
+// (timing-only builds -- no MFMAs / no fills / fills never waited for: tools/ablations/timing_switches.patch)
 #define C8_MFMA(B_, A_, C_) { C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(B_, A_, C_, 0, 0, 0); }
-#endif
 
 template <bool POINTWISE, bool SRC2>
 __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
@@ -91,11 +87,7 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
     // half-tile kinds in a buffer: 0 = A-h0, 1 = B-h0, 2 = B-h1, 3 = A-h1
 #define C8_SLOT(KT, KIND) (smem + ((((KT) & 1) << 2) + (KIND)) * C8_HALF_E)
     // stage half-tile KIND of k-tile KT (wave-uniform KT; past the end of K: the zero page)
-#if defined(C8_NO_STAGE)   // development: no fills after the prologue (timing only)
-#define C8_STAGE_GUARD(KT) if ((KT) >= 2) break;
-#else
 #define C8_STAGE_GUARD(KT)
-#endif
 #define C8_STAGE(KT, KIND)                                                                                             \
     do {                                                                                                               \
         C8_STAGE_GUARD(KT)                                                                                             \
@@ -172,13 +164,7 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(ConvArgs p) {
                 _Pragma("unroll") for (int j = 0; j < 2; j++) C8_MFMA(BF[j][ks], af[i][ks], acc[(QA) * 4 + i][(QB) * 2 + j]) \
         C8_PRIO(0);                                                                                                    \
     }
-#if defined(C8_NO_STAGE)
-#define C8_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#elif defined(C8_NO_VMWAIT)   // development: fills issued but never waited for (timing only, wrong results)
-#define C8_VMWAIT() asm volatile("s_waitcnt vmcnt(62)" ::: "memory")
-#else
 #define C8_VMWAIT() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
-#endif
 #define C8_WAIT_BARRIER()                                                                                              \
     {                                                                                                                  \
         C8_VMWAIT();                                                                                                   \

@@ -465,48 +465,9 @@ struct BottleneckArgs {
 
 constexpr int BN_THREADS = 512;  // 8 waves: two workgroups per CU give 4 waves per SIMD to hide the many short phases
 
-#ifndef SALVE_STORE_POLICY
-#define SALVE_STORE_POLICY 0   // output stores of the streaming kernels: 0 plain, 1 sc1, 2 nt, 3 sc0 sc1, 4 sc1 nt (timing builds)
-#endif
-typedef __attribute__((__ext_vector_type__(4))) unsigned u32x4;
-// 16-byte store of an output that nobody reads before the next launch
-__device__ __forceinline__ void store16_stream(uint16_t* p, uint4 v) {
-#if SALVE_STORE_POLICY == 0
-    *reinterpret_cast<uint4*>(p) = v;
-#else
-    const u32x4 d = {v.x, v.y, v.z, v.w};
-#if SALVE_STORE_POLICY == 1
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-#elif SALVE_STORE_POLICY == 2
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-#elif SALVE_STORE_POLICY == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-#endif
-#endif
-}
-
-#ifndef SALVE_BN_ABL
-#define SALVE_BN_ABL 0   // timing-only builds of bottleneck_kernel (tools/build_bn_timers.sh): 1 = no output stores, 2 = every X row reads the zero page
-#endif
-#if defined(SALVE_BN_TIMERS)
-// development build (tools/bn_phase_time.py): where a tile's cycles go, wave 0 of every workgroup, s_memtime laps summed per phase:
-// [0] first X stage's wait + barrier [1] rest of GEMM 1 [2] t1 epilogue [3] first Wb stage's wait + barrier [4] rest of GEMM 2
-// [5] t2 epilogue [6] GEMM 3 [7] tiles; inside GEMM 3, per chunk: [8] weight chunk wait + barrier [9] MFMAs + epilogue into the
-// staging tile [10] barrier + stores + barrier
-__device__ unsigned long long bn_timers[2][16];
-#define BN_STAMP_(t) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#define BN_T0() unsigned long long bn_t0_; BN_STAMP_(bn_t0_)
-#define BN_T(k) { unsigned long long t_; BN_STAMP_(t_) if (threadIdx.x == 0) atomicAdd(&bn_timers[PROJ ? 1 : 0][k], (k) == 7 ? 1ull : t_ - bn_t0_); bn_t0_ = t_; }
-#define BN_S0() unsigned long long bn_s0_; BN_STAMP_(bn_s0_)
-#define BN_S(k) { unsigned long long t_; BN_STAMP_(t_) if (threadIdx.x == 0) atomicAdd(&bn_timers[PROJ ? 1 : 0][k], t_ - bn_s0_); bn_s0_ = t_; }
-#else
-#define BN_T0()
-#define BN_T(k)
-#define BN_S0()
-#define BN_S(k)
-#endif
+// 16-byte store of an output that nobody reads before the next launch.  (Cache-policy bits on it -- sc1, nt, sc0 sc1, sc1 nt -- were
+// timed in round 4 and change nothing; the timing-only builds of this file are tools/ablations/timing_switches.patch.)
+__device__ __forceinline__ void store16_stream(uint16_t* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 
 // PROJ: the first block of layer 1 -- its input has MID channels (not 4 MID) and its shortcut is a 1x1 projection, which rides
 //       in GEMM 3 as MID more k: Y = relu([t2 | X] . [Wc | Ws]^T + (bc + bs)), the weight rows K-concatenated as the
@@ -539,10 +500,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     constexpr int EC_P = T2_E + MO * 64 + 64 * (MID + CIN) + MO * LDC_P;    // PROJ: t2 | X centre tile | weight chunk | staging
     constexpr int EA = 2 * ST1_E, EB = T1_E + 2 * BSB_E, EC = PROJ ? EC_P : T2_E + BSC_E + CS_E;
     constexpr int SMEM_E = EA > EB ? (EA > EC ? EA : EC) : (EB > EC ? EB : EC);
-#ifndef SALVE_BN_PAD_LDS
-#define SALVE_BN_PAD_LDS 0   // timing-only: extra LDS elements per workgroup (45056: one workgroup per CU instead of two)
-#endif
-    __shared__ __attribute__((aligned(1024))) uint16_t smem[SMEM_E + SALVE_BN_PAD_LDS];
+    __shared__ __attribute__((aligned(1024))) uint16_t smem[SMEM_E];
     uint16_t* T1 = smem;
     uint16_t* T2 = smem;
     uint16_t* BsB = smem + T1_E;
@@ -592,7 +550,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         res_swz[i] = (h >> 1) & 7;
     }
 
-    BN_T0();
     // ------------------------------------------------------------------ GEMM 1: t1 = relu(Xhalo . Wa^T + ba)
     {
         const uint16_t* rowp[M1 / 64];
@@ -600,7 +557,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         for (int i = 0; i < M1 / 64; i++) {
             const int h = row_base + 64 * i;
             const int hy = oy0 - 1 + h / HC, hx = ox0 - 1 + h % HC;
-            const bool ok = h < HALO && hy >= 0 && hy < p.H && hx >= 0 && hx < p.W && !((SALVE_BN_ABL & 2) && p.B > 0);
+            const bool ok = h < HALO && hy >= 0 && hy < p.H && hx >= 0 && hx < p.W;
             rowp[i] = ok ? ximg + ((long long)hy * p.W + hx) * CIN + chunk * 8 : nullptr;
         }
         const uint16_t* wrow = p.wa + (long long)row_base * CIN + chunk * 8;
@@ -636,7 +593,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             asm volatile("s_barrier" ::: "memory");
-            if (kt == 0) BN_T(0);
             const uint16_t* As = smem + (kt & 1) * ST1_E;
             const uint16_t* BsA = As + M1 * 64;
             if constexpr (!PROJ) {
@@ -668,7 +624,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             asm volatile("s_barrier" ::: "memory");  // everyone is done reading this buffer
         }
 #undef ISSUE_A
-        BN_T(1);
         ISSUE_WB(0);  // first Wb stage: lands while t1 is written (its buffer is behind t1)
         // t1 rows: MID halves = MID / 8 chunks of 16 bytes, chunk q of row h stored at slot q ^ swz(h)
 #pragma unroll
@@ -689,7 +644,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         }
     }
 
-    BN_T(2);
     // ------------------------------------------------------------------ GEMM 2: t2 = relu(3x3(t1) . Wb + bb)
     {
         f32x4 acc[RT][NT2];
@@ -707,7 +661,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (first stage: this wave's t1 stores)
             asm volatile("s_barrier" ::: "memory");
-            if (st == 0) BN_T(3);
             const uint16_t* Bst = BsB + (st & 1) * BSB_E;
 #pragma unroll
             for (int q = 0; q < STAGE_TILES; q++) {
@@ -737,7 +690,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
         }
-        BN_T(4);
 #pragma unroll
         for (int i = 0; i < RT; i++) {
             const int m = (wr * RT + i) * 16 + frag_row;  // output pixel of the tile, row-major
@@ -752,7 +704,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
         }
     }
 #undef ISSUE_WB
-    BN_T(5);
 
     // ------------------------------------------------------------------ GEMM 3 (PROJ): Y = relu([t2 | X] . [Wc | Ws]^T + b)
     if constexpr (PROJ) {
@@ -770,7 +721,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             const uint16_t* src = ox < p.W ? ximg + ((long long)oy * p.W + ox) * CIN + chunk * 8 : p.zeros;
             __builtin_amdgcn_global_load_lds((global_cptr)src, (lds_ptr)(Xc + (wave * 8 + 64 * i) * 64), 16, 0, 0);
         }
-        BN_S0();
         for (int nc = 0; nc < C4 / 64; nc++) {
 #pragma unroll
             for (int q = 0; q < KP / 64; q++)
@@ -778,7 +728,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                                                  (lds_ptr)(Wp + q * 64 * 64 + (wave * 8) * 64), 16, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // (first chunk: also orders the t2 stores)
-            BN_S(8);
             f32x4 acc[RT][2];
 #pragma unroll
             for (int i = 0; i < RT; i++)
@@ -816,7 +765,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                         pack4<true>(amax, acc[i][j] + vec4(bias));
                 }
             }
-            BN_S(9);
             __syncthreads();
             uint16_t* yimg = p.y + (long long)b * p.H * p.W * C4;
 #pragma unroll
@@ -824,18 +772,16 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const int id = tid + it * BN_THREADS;
                 const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (ox < p.W && !((SALVE_BN_ABL & 1) && p.B > 0))
+                if (ox < p.W)
                     store16_stream(yimg + ((long long)oy * p.W + ox) * C4 + nc * 64 + ch * 8, *reinterpret_cast<const uint4*>(Cp + m * LDC_P + ch * 8));
             }
             __syncthreads();  // staging and weight chunk are reused by the next chunk
-            BN_S(10);
         }
     } else
     // ------------------------------------------------------------------ GEMM 3: Y = relu(t2 . Wc^T + bc + X)
     {
         constexpr int CH_PER_ROW = 128 / 8;
         constexpr int C_ITERS = (MO * CH_PER_ROW) / BN_THREADS;
-        BN_S0();
 #pragma unroll
         for (int nc = 0; nc < C4 / 128; nc++) {
             // Wc chunk: 128 output channels x MID, as KT_MID tiles of 128 rows x 64
@@ -847,7 +793,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                                                      (lds_ptr)(BsC + q * 128 * 64 + (wave * 8 + 64 * j) * 64), 16, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // (first chunk: also orders the t2 stores)
-            BN_S(8);
             f32x4 acc[RT][4];
 #pragma unroll
             for (int i = 0; i < RT; i++)
@@ -886,7 +831,6 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                     *cell = pack4<true>(amax, acc[i][j] + vec4(bias) + vec4(r));
                 }
             }
-            BN_S(9);
             __syncthreads();
             uint16_t* yimg = p.y + (long long)b * p.H * p.W * C4;
 #pragma unroll
@@ -894,15 +838,12 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const int id = tid + it * BN_THREADS;
                 const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (ox < p.W && !((SALVE_BN_ABL & 1) && p.B > 0))
+                if (ox < p.W)
                     store16_stream(yimg + ((long long)oy * p.W + ox) * C4 + nc * 128 + ch * 8, *reinterpret_cast<const uint4*>(Cs + m * LDC + ch * 8));
             }
             __syncthreads();  // staging and Wc tile are reused by the next chunk
-            BN_S(10);
         }
     }
-    BN_T(6);
-    BN_T(7);
     report_range(p.status, amax);
 }
 
@@ -982,14 +923,6 @@ bool check_op(const salve_resnet_op_t& o) {
 
 extern "C" {
 
-#if defined(SALVE_BN_TIMERS)
-// development build only: reads (and clears) bottleneck_kernel's phase timers: out[2][16], [0] the plain form, [1] the PROJ form
-int salve_debug_bn_timers(unsigned long long* out) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bn_timers), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
-    unsigned long long zero[32] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(bn_timers), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 
 void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,

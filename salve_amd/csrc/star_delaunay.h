@@ -578,9 +578,6 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
     //    A window that covers the whole bounding box and is still empty proves s->a a hull edge.
     int M = SD_WINDOW_MARGIN;
     int wy0, wy1, wx0, wx1;
-#if defined(SD_ABL_NO_WINDOW)   // development: timing only -- every query that reaches the sweeps is answered "hull edge"
-    if (g.nlanes > 1) return false;
-#endif
     for (;;) {
         wy0 = (sy < ay ? sy : ay) - M; wy1 = (sy > ay ? sy : ay) + M;
         wx0 = (sx < ax ? sx : ax) - M; wx1 = (sx > ax ? sx : ax) + M;
@@ -630,11 +627,7 @@ SD_FN bool sd_apex(const SdGrid& g, int sx, int sy, int ax, int ay, int dir, int
             if (ly1 < (float)cy1) cy1 = (int)ly1;
             if (lx1 < (float)cx1) cx1 = (int)lx1;
         }
-#if defined(SD_ABL_NO_SLOW)   // development (tools/densify_ablation.py): timing only, the result is wrong
-        if (false) {
-#else
         if (cy1 > wy1 || cy0 < wy0 || cx0 < wx0 || cx1 > wx1) {
-#endif
             SD_COUNT(apex_slow);
             // one sweep over the circle's rows: what the window already covered is cut away by the circle, cheaply
             sd_scan_rows<true>(g, edge, cy0, cy1, 1, cx0, cx1, &best);

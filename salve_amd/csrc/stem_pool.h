@@ -158,11 +158,7 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) 
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if defined(STEM_NO_MFMA)
-        for (int kh = 0; kh < 0; kh++) {
-#else
         for (int kh = 0; kh < 7; kh++) {
-#endif
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 act8 af[8], bfr[4];
@@ -181,12 +177,7 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) 
         float4 bias[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) bias[j] = lds_read_f4(bias_s + j * 16 + 4 * frag_q_);
-#if !defined(STEM_NO_LOAD)
         if (k + 1 < n_mine) issue_patch(b_next, s_next);       // ... so the next one streams in under the rest of this strip
-#endif
-#if defined(STEM_NO_POOL)
-        if (acc[0][0][0] == 12345.678f)
-#endif
         {
             // (the LDS addresses of the hand-over are recomputed per strip from an opaque copy of the lane's coordinates: hoisted out
             //  of the strip loop they cost 77 spilled registers, reloaded inside the MFMA loop)
