@@ -451,9 +451,7 @@ SD_FN void sd_share_best(const SdGrid& g, const SdEdge& e, SdBest* best, int* sh
         }
         // (`changed` is never empty here, and the minimum's own lane is a contender in exact arithmetic; should the float thinning
         //  ever drop every lane -- a NaN lambda would --, the candidate shared so far stays instead of an apex of (-1, -1))
-#if !defined(SD_NO_SHARE_GUARD)   // (tools/build_slp.sh builds a probe library without the guard: does the fence of RasterEmit fire then?)
         if (w.px < 0) return;
-#endif
         sd_best_set(*best, e, w.px, w.py, w.lam);
         *shared_x = w.px;
         *shared_y = w.py;

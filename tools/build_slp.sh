@@ -8,11 +8,9 @@ cd "$(dirname "$0")/../salve_amd/csrc"
 mkdir -p ../../tools/_abl /tmp/slp_obj
 F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC"
 hipcc $F -c bev_render.hip -o /tmp/slp_obj/bev_render.o &
-hipcc $F -DSD_NO_SHARE_GUARD -c bev_render.hip -o /tmp/slp_obj/bev_render_ng.o &
 hipcc $F -fno-slp-vectorize -c layout.hip -o /tmp/slp_obj/layout.o &
 hipcc $F -c resnet.hip -o /tmp/slp_obj/resnet.o &
 hipcc $F -c abi.hip -o /tmp/slp_obj/abi.o &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_abl/libsalve_slp.so /tmp/slp_obj/bev_render.o /tmp/slp_obj/layout.o /tmp/slp_obj/resnet.o /tmp/slp_obj/abi.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_abl/libsalve_slp_noguard.so /tmp/slp_obj/bev_render_ng.o /tmp/slp_obj/layout.o /tmp/slp_obj/resnet.o /tmp/slp_obj/abi.o
-ls -la ../../tools/_abl/libsalve_slp.so ../../tools/_abl/libsalve_slp_noguard.so
+ls -la ../../tools/_abl/libsalve_slp.so
