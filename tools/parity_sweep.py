@@ -1,5 +1,5 @@
 """One-off wide parity sweep (GPU box): N random hypotheses x {floor, ceiling} over several panoramas, final BEV images
-bit for bit against the oracle's exact mode, oracle renders in a process pool.  python tools/parity_sweep.py [N] [procs]"""
+bit for bit against the oracle's exact mode, oracle renders in a process pool.  python tools/parity_sweep.py [N] [procs] [scene] [seed]"""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -10,8 +10,8 @@ import numpy as np
 def oracle_one(args):
     from oracle import bev_oracle as bo
     from salve_amd import synthetic
-    pi, surface, R, t = args
-    rgb, depth = synthetic.make_pano(pi)
+    pi, surface, R, t, scene = args
+    rgb, depth = synthetic.make_pano(pi, scene=scene)
     a = bo.xyzrgb_from_arrays(depth, rgb, bo.floor_ceiling_z_range(surface))
     a, _ = bo.pose_pair(a, a[:1], R, t)
     res = bo.render_bev_image(a, mode="exact")
@@ -24,17 +24,20 @@ if __name__ == "__main__":
     from salve_amd.rasteriser import BevRasteriser, pack_hypotheses
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 96
     procs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    scene = sys.argv[3] if len(sys.argv) > 3 else "box"
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 123
     P = 6
-    hyp = synthetic.make_hypotheses(N, P, seed=123)
+    hyp = synthetic.make_hypotheses(N, P, seed=seed)
+    hyp.t[::7] *= 2.0     # some clouds half out of the window
     surf = np.arange(N) % 2
-    jobs = [(int(hyp.i1[j]), "floor" if surf[j] == 0 else "ceiling", hyp.R[j], hyp.t[j]) for j in range(N)]
+    jobs = [(int(hyp.i1[j]), "floor" if surf[j] == 0 else "ceiling", hyp.R[j], hyp.t[j], scene) for j in range(N)]
     t0 = time.time()
     with mp.get_context("spawn").Pool(procs) as pool:
         ref = pool.map(oracle_one, jobs, chunksize=2)
     print(f"oracle: {time.time() - t0:.0f} s for {N} renders", flush=True)
     dev = torch.device("cuda:0")
     ras = BevRasteriser(dev)
-    panos = [synthetic.make_pano(i) for i in range(P)]
+    panos = [synthetic.make_pano(i, scene=scene) for i in range(P)]
     d_rgb, d_depth = ras.upload_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     h = pack_hypotheses(hyp.i1, surf, hyp.R, hyp.t, np.ones(N))
     bad = 0
@@ -46,5 +49,7 @@ if __name__ == "__main__":
             if not np.array_equal(got[j], exp):
                 bad += 1
                 print("MISMATCH rep", rep, "render", j, jobs[j][:2], int((got[j] != exp).any(-1).sum()), "pixels", flush=True)
-    print("renders compared:", 3 * N, "mismatches:", bad)
+    from salve_amd import status
+    status.check(dev, "parity_sweep")
+    print(f"scene {scene}, seed {seed}: renders compared:", 3 * N, "mismatches:", bad)
     sys.exit(1 if bad else 0)
