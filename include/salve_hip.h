@@ -292,6 +292,8 @@ typedef struct {
 #define SALVE_RESNET_CHAIN_EXPAND_ONLY 128 /* expand_chain_kernel without the next block's first convolution */
 #define SALVE_RESNET_CHAIN_16_WAVES 256  /* its 16-wave / 256-pixel-tile form for the 128-channel shapes */
 #define SALVE_RESNET_CHAIN_NO_SPLIT 512  /* its 8-wave form for the 256-channel shapes too */
+#define SALVE_RESNET_CHAIN_STORE_ALL 1024 /* every pixel of a stage's last block output is stored (default: only the even rows and columns
+                                             that its one reader, the next stage's stride-2 projection shortcut, samples) */
 
 /* Creates a handle that owns device copies of the (host) weight blobs.  NULL on failure.  flags: SALVE_RESNET_* (0). */
 void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,

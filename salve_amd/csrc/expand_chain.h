@@ -59,6 +59,9 @@ struct ChainArgs {
     const float* ba;
     const uint16_t* zeros;
     int M, n_tiles;
+    int y_even_w;          // 0: every row of Y is stored.  W > 0 (r5): the images are W x W and Y's only reader besides the chained
+                           // convolution is a stride-2 projection shortcut (in2_buf, stride2 = 2) -- only the pixels with even row AND
+                           // even column are ever read, so only those are written: three quarters of Y's bytes never cross HBM
     int32_t* status;
     int dbg;   // ABLATION BUILD ONLY (-DSALVE_BUILD_ABLATIONS; timing only, wrong results): 1 = no weight LDS-DMA after the prologue,
                // 2 = no item LDS-DMA, 4 = no Y stores.  The product build compiles the tests of these bits out (CHAIN_DBG).
@@ -223,6 +226,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
     int c_slot = 0, c_cb = 0, c_ab = 0;            // consumer cursor: ring slot, weight buffers of the current RES step
     int prev_slot = 0, prev_ab = 0, prev_nc = 0;   // the previous RES step's Y chunk (GEMM 1' and the store run one step late)
     long long prev_m0 = 0;
+    constexpr bool YEVEN = CHAIN && MIDN != MID;   // only a stage's last block can have y_even_w set (the host checks): the others carry no mask
+    static_assert(PIECES <= 16, "two keep masks in one register");
+    uint32_t keeps = ~0u;                          // y_even_w: bit `it` (16 + `it`) = this lane's piece `it` of the current (previous) tile belongs to a stored pixel
+    auto tile_keep = [&](long long m0_) -> uint32_t {
+        if (!YEVEN || p.y_even_w == 0) return ~0u;
+        uint32_t k = 0;
+#pragma unroll
+        for (int it = 0; it < PIECES; it++) {
+            const long long m = m0_ + ((it * (NL * 64) + sw * 64 + lane) >> 2);
+            const int ox = (int)(m % p.y_even_w), oy = (int)((m / p.y_even_w) % p.y_even_w);
+            k |= (((ox | oy) & 1) == 0 ? 1u : 0u) << it;
+        }
+        return k;
+    };
     bool tail = false;                             // the producer has run past the end of the stream: waits are full from here on
 
     // GEMM 1' of the previous step's Y chunk, and the tile's t1' when that chunk was its last
@@ -277,14 +294,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
         uint4 v[PIECES];
 #pragma unroll
         for (int it = 0; it < PIECES; it++) v[it] = __builtin_bit_cast(uint4, vh[it]);
-        if (prev_m0 + ROWS <= p.M) {       // a full tile (wave-uniform): no row guards
+        if (prev_m0 + ROWS <= p.M && (!YEVEN || p.y_even_w == 0)) {       // a full tile, every row stored (wave-uniform): no row guards
 #pragma unroll
             for (int it = 0; it < PIECES; it++) *reinterpret_cast<uint4*>(ybase + piece_goff[it]) = v[it];
         } else {
 #pragma unroll
             for (int it = 0; it < PIECES; it++) {
                 const int row = (it * (NL * 64) + sw * 64 + lane) >> 2;
-                if (prev_m0 + row < p.M) *reinterpret_cast<uint4*>(ybase + piece_goff[it]) = v[it];
+                if (prev_m0 + row < p.M && (!YEVEN || ((keeps >> (16 + it)) & 1u))) *reinterpret_cast<uint4*>(ybase + piece_goff[it]) = v[it];
             }
         }
     };
@@ -297,6 +314,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
 
     for (int ti = 0; ti < n_my; ti++) {
         const long long m0 = ((long long)b + (long long)ti * G) * ROWS;
+        if (YEVEN && !loader) keeps = (keeps & 0xffff0000u) | (tile_keep(m0) & 0xffffu);
         // ---------------------------------------------------------------- A items: the tile's A fragments -> registers
 #pragma unroll
         for (int k = 0; k < KA; k++) {
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void expand_chain_kernel(ChainArgs
                 if (tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IT_DMA + WC_DMA + WA_DMA) : "memory");
             }
-            prev_slot = c_slot; prev_ab = c_ab; prev_nc = nc; prev_m0 = m0;
+            prev_slot = c_slot; prev_ab = c_ab; prev_nc = nc; prev_m0 = m0; if constexpr (YEVEN) keeps = (keeps & 0xffffu) * 0x10001u;
             if (++c_cb == NB_C) c_cb = 0;
             if (++c_ab == NB_A) c_ab = 0;
             if (++c_slot == R) c_slot = 0;

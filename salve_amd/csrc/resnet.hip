@@ -866,6 +866,7 @@ struct ResnetHandle {
     int n_cus = 256;
     int chain_split = 1;                  // SALVE_RESNET_CHAIN_NO_SPLIT: the 8-wave form for the 256-channel shapes too
     int chain_dbg = 0, chain_waves = 8;   // chain_dbg: ablation build only (timing-only switches of expand_chain_kernel); SALVE_RESNET_CHAIN_16_WAVES
+    std::vector<int> y_even;              // per op: 1 = the chained expand convolution stores only Y's even pixels (expand_chain.h: y_even_w)
 };
 
 // expand_chain_kernel shapes: (MID, MIDN) of the chained form, MID of the expand-only form
@@ -1034,6 +1035,25 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
                 if (next) h->chain[i] = 2;
             }
         }
+        // (r5) A chained block whose output Y is otherwise read only by a stride-2 projection shortcut (the last block of a stage: the
+        // next block's first convolution is computed in the kernel, its shortcut samples Y at even rows and columns) stores only those
+        // pixels: 3/4 of Y's bytes never cross HBM.  Every reader of the buffer up to its next writer is checked.
+        h->y_even.assign(h->ops.size(), 0);
+        for (size_t i = 0; i < h->ops.size(); i++) {
+            if (h->chain[i] != 2 || (flags & SALVE_RESNET_CHAIN_STORE_ALL)) continue;
+            const salve_resnet_op_t& c = h->ops[i];
+            if (c.Ho != c.Wo || (c.Ho & 1) || h->ops[i + 1].Cout == c.Cin) continue;   // expand_chain_kernel: YEVEN = MIDN != MID
+            bool ok = true, any = false;
+            for (size_t k = i + 2; k < h->ops.size(); k++) {
+                const salve_resnet_op_t& o = h->ops[k];
+                if (o.in_buf == c.out_buf || (o.op == SALVE_OP_CONV && o.res_buf == c.out_buf)) { ok = false; break; }
+                if (o.op == SALVE_OP_CONV && o.in2_buf == c.out_buf) {
+                    if (o.stride2 == 2 && o.Hi2 == c.Ho && o.Wi2 == c.Wo) any = true; else { ok = false; break; }
+                }
+                if (o.op != SALVE_OP_AVGPOOL_FC && o.out_buf == c.out_buf) break;
+            }
+            if (ok && any) h->y_even[i] = 1;
+        }
         h->chain_waves = (flags & SALVE_RESNET_CHAIN_16_WAVES) ? 16 : 8;
         h->chain_split = (flags & SALVE_RESNET_CHAIN_NO_SPLIT) ? 0 : 1;
 #ifdef SALVE_BUILD_ABLATIONS   // development build only: timing-only switches of expand_chain_kernel (they compute WRONG results)
@@ -1146,6 +1166,7 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             if (M > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
             a.M = (int)M;
             a.status = status;
+            a.y_even_w = h->y_even[oi] ? o.Wo : 0;
             a.dbg = h->chain_dbg;
             const int mid = o.Cin, midn = chained ? on.Cout : 0;
             // SALVE_CHAIN_WAVES=16: 16 waves, tiles of 256 pixels, where the registers allow it (<= 128 per lane).  Four waves per SIMD

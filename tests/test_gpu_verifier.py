@@ -310,13 +310,16 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(layer
     x = torch.randn(batch, 224, 224, cin).to(torch.float16).to(DEV)
     x[..., (6 if layers == 50 else 12):] = 0
     outs = {}
-    for mode in ("0", "1", "2", "2w", "2n", "1n"):
+    for mode in ("0", "1", "2", "2w", "2n", "1n", "2a", "2na"):
         flags = {"0": _lib.RESNET_NO_CHAIN, "1": _lib.RESNET_CHAIN_EXPAND_ONLY, "2": 0}[mode[0]]
         flags |= _lib.RESNET_CHAIN_16_WAVES if mode.endswith("w") else 0    # "2w": the 16-wave / 256-pixel-tile variant
-        flags |= _lib.RESNET_CHAIN_NO_SPLIT if mode.endswith("n") else 0    # "n": no channel split (8 waves) for the 256-channel shapes
+        flags |= _lib.RESNET_CHAIN_NO_SPLIT if "n" in mode else 0           # "n": no channel split (8 waves) for the 256-channel shapes
+        flags |= _lib.RESNET_CHAIN_STORE_ALL if mode.endswith("a") else 0   # "a": the last block of layer 2 stores every pixel of its output
         eng = hip_resnet.HipResNet(model.state_dict(), layers, torch.device(DEV), flags=flags)
         for rep in range(3):                             # a misplaced wait in a ring shows up as a rare wrong tile: repeat
-            o = eng.forward_nhwc(x).clone()
+            if eng._ws is not None:
+                eng._ws[: eng._ws.numel() & ~1].view(torch.int16).fill_(0x7E00)  # fp16 NaN in every activation buffer: the pixels the default build leaves
+            o = eng.forward_nhwc(x).clone()              # unwritten (odd rows / columns of layer 2's output) must never be read
             torch.cuda.synchronize()
             assert torch.isfinite(o).all()
             if mode in outs:
@@ -327,6 +330,7 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(layer
     assert torch.equal(outs["2"], outs["0"]), "chained kernel differs from the implicit-GEMM path"
     assert torch.equal(outs["2w"], outs["0"]), "16-wave chained kernel differs from the implicit-GEMM path"
     assert torch.equal(outs["2n"], outs["0"]) and torch.equal(outs["1n"], outs["0"]), "8-wave form of the 256-channel shapes differs"
+    assert torch.equal(outs["2a"], outs["0"]) and torch.equal(outs["2na"], outs["0"]), "store-all form differs"
 
 
 def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool():

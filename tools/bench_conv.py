@@ -10,6 +10,10 @@ import numpy as np, torch
 from salve_amd import _lib
 from salve_amd.models import hip_resnet
 
+hip_resnet.CHUNK_MAJOR_K = os.environ.get("SALVE_K_ORDER", "") == "chunk"   # K order of the 3 x 3 shapes (hip_resnet._Builder.conv)
+POWER = os.environ.get("SALVE_BENCH_POWER", "") == "1"                        # board power and clock while each shape loops for 3 s
+if POWER:
+    import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 DEV = "cuda:0"
 lib = _lib.load()
@@ -80,6 +84,8 @@ for name, cin, cout, k, stride, pad, hw, res, src2 in SHAPES:
     out = view[: B * ho * ho * cout].float()
     flop = 2.0 * B * ho * ho * macs
     tot += us
-    print(f"{name:30s} {us:8.1f} us  {flop / us / 1e6:7.0f} TFLOP/s   sum {float(out.double().sum()):.6e} absmax {float(out.abs().max()):.4f}", flush=True)
+    pw = bench.power_probe(run, 3.0) if POWER else None
+    print(f"{name:30s} {us:8.1f} us  {flop / us / 1e6:7.0f} TFLOP/s   sum {float(out.double().sum()):.6e} absmax {float(out.abs().max()):.4f}"
+          + (f"   {pw['power_w']:.0f} W {pw['sclk_mhz']:.0f} MHz" if pw else ""), flush=True)
     lib.salve_resnet_destroy(h)
 print(f"total {tot:.1f} us  (SALVE_RESNET_FLAGS={os.environ.get('SALVE_RESNET_FLAGS', '0')})")

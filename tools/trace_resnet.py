@@ -13,6 +13,7 @@ torch.manual_seed(0)
 layers = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 mods = ["floor_rgb_texture"] if layers != 152 else ["ceiling_rgb_texture", "floor_rgb_texture"]
 model = EarlyFusionCEResnet(layers, False, 2, SimpleNamespace(modalities=mods)).eval()
+hip_resnet.CHUNK_MAJOR_K = os.environ.get("SALVE_K_ORDER", "") == "chunk"
 eng = model.compiled(dev, flags=int(os.environ.get("SALVE_RESNET_FLAGS", "0")))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 if len(sys.argv) > 2:
