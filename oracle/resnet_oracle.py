@@ -7,6 +7,9 @@ Bottleneck (expansion 4, stride on the 3x3 conv) / BasicBlock, blocks [3,4,6,3] 
 [3,4,6,3] (34); downsample = 1x1 conv(stride) + BN on the first block of a stage; BN eps 1e-5 (eval mode: running
 statistics); maxpool 3x3/2 pad 1; AdaptiveAvgPool(1); the 1000-way resnet.fc and resnet.conv1 are present in the
 checkpoint but bypassed (early_fusion.py:20,67,81).
+Cross-check (round 5): HuggingFace `transformers.ResNetModel` -- an independent implementation of the same published network, in the
+image -- loaded with the same tensors agrees with `forward` to float32 rounding for ResNet-18 / 34 / 50 / 152
+(tests/test_oracle_hf_resnet.py).  That pins the STRUCTURE against a second implementation; it is still not torchvision itself.
 """
 
 from __future__ import annotations
