@@ -72,7 +72,8 @@ typedef struct {
     int32_t bev_h, bev_w;       /* BEVParams.img_h + 1, img_w + 1 (:292-293); 501, 501 */
     int32_t mask_k;             /* box-filter size of remove_hallucinated_content; 11 */
     float depth_scale;          /* uint16 depth -> metres, applied in float32 (:367); 0.001f */
-    int32_t out_flags;          /* 0 for render_bev_image; 1: no vertical flip, 2: no mask (plain interpolation) */
+    int32_t out_flags;          /* 0 for render_bev_image; 1: no vertical flip, 2: no mask (plain interpolation), 4: the renders of a
+                                   launch are densified in the order given (default: the costly ones first -- same images, shorter tail) */
     double win_xmin, win_xmax, win_ymin, win_ymax; /* prune_to_2d_bbox window, inclusive (:38-45); -5, 5, -5, 5 */
     double img_tx, img_ty, img_scale; /* bevimg_Sim2_world: (p + t) * s (bevparams.py:69-78); 5, 5, 50 */
     double rot_pre[4];          /* rotmat2d(-90), row-major float64 exactly as numpy computes it (:443) */

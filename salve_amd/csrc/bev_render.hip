@@ -79,7 +79,7 @@ struct DevCfg {
     double rp00, rp01, rp10, rp11;
     double zlo[2], zhi[2], zmin;
     int nslices;
-    int out_flags;  // 1: do not flip the image vertically, 2: no hallucination mask (plain interpolation)
+    int out_flags;  // 1: do not flip the image vertically, 2: no hallucination mask (plain interpolation), 4: densify in the given order
     int dbg_flags;  // development only: 1 = skip the star phase, 2 = walk stars but do not rasterise
 };
 
@@ -312,6 +312,66 @@ static int ensure_star_table() {
     return SALVE_OK;
 }
 
+// ---- longest renders first (r5).  A launch of n renders is n / 512 rounds of resident workgroups, dispatched in the order of their
+// ids; renders differ in cost, and the launch ends with a tail in which CUs run dry behind the last, arbitrary renders.  With the
+// costly renders dispatched first the tail is made of cheap ones: densify -4 ... -5 % on every synthetic scene (box 14.04 -> 13.32 ms
+// per 4096, cluttered 19.24 -> 18.43, noisy 20.12 -> 19.64; tools/densify_order_probe.py), identical images -- renders are independent.
+// The cost estimate is a count the splat's occupancy bitmap gives for 32 KB of reads per render: sites with two or more of their four
+// neighbours missing (outline and isolated sites: the ones whose walks are long; the plain site or point count does not predict the
+// cluttered / noisy scenes, and of five such counts this one was good on all three scenes).
+// bev_cost_kernel: one workgroup per render -> cost[rid]; bev_order_kernel: ONE workgroup, counting sort by cost, descending, into
+// order[] (ties in any order: the atomics of the scatter decide, nothing observable depends on it).
+constexpr int DENSIFY_ORDERED = 256;      // DensifyCfg::out_flags, set by bev_stage only: order[] is valid
+constexpr int ORDER_BINS = 1024;
+constexpr int ORDER_MIN_RENDERS = 640;    // 512 renders are resident at once (two workgroups per CU): nothing to order below that
+
+__global__ __launch_bounds__(256) void bev_cost_kernel(const uint32_t* __restrict__ bitmaps_all, int ntiles, int32_t* __restrict__ cost) {
+    const int rid = blockIdx.x, tid = threadIdx.x;
+    const uint4* bm_occ = reinterpret_cast<const uint4*>(bitmaps_all + (size_t)rid * 2 * ntiles * TILE_H * TILE_WORDS);
+    int cnt = 0;
+    for (int i = tid; i < ntiles * TILE_H; i += 256) {
+        const int r = i % TILE_H;
+        const uint4 o = bm_occ[i];
+        const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);        // rows and columns beyond the tile: taken as present
+        const uint4 a = r > 0 ? bm_occ[i - 1] : ones, b = r < TILE_H - 1 ? bm_occ[i + 1] : ones;
+        const uint32_t w[4] = {o.x, o.y, o.z, o.w}, up[4] = {a.x, a.y, a.z, a.w}, dn[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t R = (w[k] >> 1) | (k < 3 ? w[k + 1] << 31 : 0x80000000u), L = (w[k] << 1) | (k > 0 ? w[k - 1] >> 31 : 1u);
+            const uint32_t three = (L & R & (up[k] | dn[k])) | (up[k] & dn[k] & (L | R));   // at least three of the four neighbours are sites
+            cnt += __popc(w[k] & ~three);
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    __shared__ int part[4];
+    if ((tid & 63) == 0) part[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) cost[rid] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(1024) void bev_order_kernel(const int32_t* __restrict__ cost, int n, int32_t* __restrict__ order) {
+    __shared__ int bins[ORDER_BINS];
+    __shared__ int cmax;
+    const int tid = threadIdx.x;
+    bins[tid] = 0;
+    if (tid == 0) cmax = 1;
+    __syncthreads();
+    int m = 1;
+    for (int i = tid; i < n; i += 1024) m = max(m, cost[i]);
+    atomicMax(&cmax, m);
+    __syncthreads();
+    const float scale = (float)(ORDER_BINS - 1) / (float)cmax;
+    auto bin_of = [&](int c) { return ORDER_BINS - 1 - min(ORDER_BINS - 1, max(0, (int)((float)c * scale))); };   // costly first
+    for (int i = tid; i < n; i += 1024) atomicAdd(&bins[bin_of(cost[i])], 1);
+    __syncthreads();
+    if (tid == 0) {   // exclusive scan of 1024 counters by one lane: a microsecond
+        int acc = 0;
+        for (int b = 0; b < ORDER_BINS; b++) { const int c = bins[b]; bins[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&bins[bin_of(cost[i])], 1)] = i;
+}
+
 // DEV = false is the product kernel: the development outputs (mask image, work counters) and the development flags of the
 // configuration (phases switched off for timing, tools/densify_*.py) are compiled OUT -- their pointers and tests kept a dozen
 // scalar registers live through every loop of a kernel that runs at the limit of the scalar register file (100 spills), and
@@ -336,7 +396,14 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     unsigned long long* tri_cache = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(scal + N_SCAL) + 7) & ~(uintptr_t)7);  // SD_CACHE_SIZE entries
 
     __shared__ int list_wave_total[DENSIFY_THREADS / 64];
-    const int rid = blockIdx.x;
+    // (bev_order_kernel: the costly renders first.  The order array lies behind the bitmaps of the launch's renders -- the workspace's
+    //  key image: [cost n][order n] -- and is named by a flag bit instead of a pointer argument: one more live scalar register pair moved
+    //  eight spill reloads into the lean-walk loop, tools/densify_spills.py)
+    int rid = blockIdx.x;
+    if (c.out_flags & DENSIFY_ORDERED) {
+        const size_t words_per_render = (size_t)2 * ((c.W + TILE_W - 1) / TILE_W) * ((c.H + TILE_H - 1) / TILE_H) * TILE_H * TILE_WORDS;
+        rid = reinterpret_cast<const int32_t*>(bitmaps_all + (size_t)gridDim.x * words_per_render)[gridDim.x + blockIdx.x];
+    }
     const int flip = (c.out_flags & 1) ? -1 : H - 1;
     uint32_t* bev = bev_all + (size_t)rid * H * W;
     auto pixi = [&](int x, int y) -> uint32_t { return (uint32_t)((flip >= 0 ? flip - y : y) * W + x); };   // pixel (x, y) of the output image, 32-bit element index (RasterEmit::pix)
@@ -1077,7 +1144,16 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         if (tab_status != SALVE_OK) return tab_status;
         static std::mutex mu;
         static size_t attr[2][64] = {{0}};
-        const DensifyCfg dc = {d.H, d.W, d.wpr, d.mask_half, d.out_flags, d.dbg_flags};
+        DensifyCfg dc = {d.H, d.W, d.wpr, d.mask_half, d.out_flags & 255, d.dbg_flags};
+        // the order of the renders inside the launch (bev_cost_kernel / bev_order_kernel above); its two int32 arrays live in the
+        // workspace's key image, which only the single-render utility paths use
+        if (!(d.out_flags & 4) && n >= ORDER_MIN_RENDERS && (size_t)2 * n * sizeof(int32_t) <= npx * sizeof(uint32_t)) {
+            int32_t* cost = reinterpret_cast<int32_t*>(ws.keys);
+            hipLaunchKernelGGL(bev_cost_kernel, dim3(n), dim3(256), 0, s, ws.bitmaps, tiles_x * tiles_y, cost);
+            hipLaunchKernelGGL(bev_order_kernel, dim3(1), dim3(1024), 0, s, cost, n, cost + n);
+            SALVE_HIP_CHECK(hipGetLastError());
+            dc.out_flags |= DENSIFY_ORDERED;
+        }
         if (dbg_mask || dbg_stats || d.dbg_flags) {   // development outputs or flags: the instantiation that has them
             const int st = ensure_lds(bev_densify_kernel<true>, lds, attr[1], mu);
             if (st != SALVE_OK) return st;
@@ -1091,7 +1167,6 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         }
         SALVE_HIP_CHECK(hipGetLastError());
     }
-    (void)npx;
     return SALVE_OK;
 }
 

@@ -137,7 +137,7 @@ class RenderVerifyPipeline:
         self._densified[0] = self._panos_ready
 
     # ------------------------------------------------------------------ hypotheses
-    def prepare(self, hyp: HypothesisTable, layouts=None):
+    def prepare(self, hyp: HypothesisTable, layouts=None, order: Optional[np.ndarray] = None):
         """Upload the render table and the tile job tables of a hypothesis shard (once, outside the timed loop).
         `layouts` (salve_amd.layout.FusedLayouts; required iff the model's modalities include "layout"): the posed layout of
         panorama i1 per hypothesis and the own layout of every panorama -- the geometry is posed on the host exactly as
@@ -150,7 +150,13 @@ class RenderVerifyPipeline:
         N, S = len(hyp), len(self.surfaces)
         surf_ids = [SURFACES[s] for s in self.surfaces]
         i1 = np.asarray(hyp.i1).astype(np.int64)
-        order, rank = render_order(i1, self.chunk)  # rank[j]: position of hypothesis j in the render order of the whole table
+        if order is None:
+            order, rank = render_order(i1, self.chunk)  # rank[j]: position of hypothesis j in the render order of the whole table
+        else:   # development (tools/densify_order_probe.py): a caller's render order; it must keep every hypothesis inside its chunk
+            order = np.asarray(order).astype(np.int64)
+            assert sorted(order.tolist()) == list(range(N)) and bool((order // self.chunk == np.arange(N) // self.chunk).all())
+            rank = np.empty(N, dtype=np.int64)
+            rank[order] = np.arange(N)
         rows = pack_hypotheses(np.repeat(i1[order], S), np.tile(surf_ids, N), np.repeat(np.asarray(hyp.R)[order], S, axis=0),
                                np.repeat(np.asarray(hyp.t)[order], S, axis=0), np.ones(N * S))
         j = np.arange(N)

@@ -463,6 +463,40 @@ def test_scatter_then_densify_equals_render_and_the_sparse_image_is_the_oracles(
         assert int(counts[k]) == res["img_xy"].shape[0]
 
 
+def test_costly_renders_first_is_the_same_images(setup):
+    """From 640 renders per launch on, the densify stage dispatches the costly renders first (bev_cost_kernel / bev_order_kernel:
+    a count from the occupancy bitmaps, a counting sort, an index array behind the bitmaps in the workspace; out_flags bit 4 keeps
+    the given order).  Renders are independent: both orders give the same images, image for image -- over a launch that mixes cheap
+    renders (clouds half out of the window, empty renders of a panorama that is not in the batch) with full ones."""
+    ras, panos, d_rgb, d_depth, hyp = setup
+    n = 700
+    big = synthetic.make_hypotheses(n, len(panos), seed=4)
+    big.t[::5] *= 3.0                       # mostly out of the window
+    i1 = np.asarray(big.i1).copy()
+    i1[7::50] = len(panos) + 3              # bad rows: empty images, SALVE_STATUS_BAD_HYPOTHESIS
+    hd = ras.upload_hypotheses(pack_hypotheses(i1, np.arange(n) % 2, big.R, big.t, np.ones(n)))
+    a = torch.empty((n, *ras.bev_hw), dtype=torch.int32, device=ras.device)
+    b = torch.empty_like(a)
+    try:
+        ras.scatter(d_rgb, d_depth, hd, n, a)
+        ras.densify(n, a)                   # costly first
+        ras.cfg.out_flags = 4
+        ras.scatter(d_rgb, d_depth, hd, n, b)
+        ras.densify(n, b)                   # as given
+    finally:
+        ras.cfg.out_flags = 0
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.SalveHipError, match="panorama outside"):
+        ras.check("the bad rows")
+    assert torch.equal(a, b)
+    assert int((a[0] != 0).sum()) > 10000 and int((a[7] != 0).sum()) == 0
+    # and the same images as a launch below the threshold, which is never reordered
+    few, _ = ras.render(d_rgb, d_depth, hd, 16)
+    assert torch.equal(few, a[:16])
+    with pytest.raises(_lib.SalveHipError, match="panorama outside"):   # (render 7 of the 16 is a bad row too)
+        ras.check("the bad row again")
+
+
 def test_panorama_index_follows_the_depth_tensor(setup):
     """The pose-independent panorama index (block boxes) is built on first use and kept with the depth TENSOR OBJECT
     (BevRasteriser.pano_index): a slice or a copy builds its own; depth maps overwritten in place through torch (the tensor's
