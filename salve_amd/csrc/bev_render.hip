@@ -323,7 +323,9 @@ static int ensure_star_table() {
 // order[] (ties in any order: the atomics of the scatter decide, nothing observable depends on it).
 constexpr int DENSIFY_ORDERED = 256;      // DensifyCfg::out_flags, set by bev_stage only: order[] is valid
 constexpr int ORDER_BINS = 1024;
-constexpr int ORDER_MIN_RENDERS = 640;    // 512 renders are resident at once (two workgroups per CU): nothing to order below that
+constexpr int ORDER_MIN_RENDERS = 1025;   // more than two rounds of the 512 resident workgroups.  Measured (tools/densify_order_threshold.py, costly
+                                          // first against as given): 1536 ... 4096 renders -2.2 ... -6.9 % on the box and the noisy scene; at 640 / 768 /
+                                          // 1024 renders -7 ... +4 % with either sign (1024 = exactly two rounds: +3.5 % box, config 5's launches +5 %)
 
 __global__ __launch_bounds__(256) void bev_cost_kernel(const uint32_t* __restrict__ bitmaps_all, int ntiles, int32_t* __restrict__ cost) {
     const int rid = blockIdx.x, tid = threadIdx.x;

@@ -464,12 +464,12 @@ def test_scatter_then_densify_equals_render_and_the_sparse_image_is_the_oracles(
 
 
 def test_costly_renders_first_is_the_same_images(setup):
-    """From 640 renders per launch on, the densify stage dispatches the costly renders first (bev_cost_kernel / bev_order_kernel:
+    """From 1025 renders per launch on, the densify stage dispatches the costly renders first (bev_cost_kernel / bev_order_kernel:
     a count from the occupancy bitmaps, a counting sort, an index array behind the bitmaps in the workspace; out_flags bit 4 keeps
     the given order).  Renders are independent: both orders give the same images, image for image -- over a launch that mixes cheap
     renders (clouds half out of the window, empty renders of a panorama that is not in the batch) with full ones."""
     ras, panos, d_rgb, d_depth, hyp = setup
-    n = 700
+    n = 1100
     big = synthetic.make_hypotheses(n, len(panos), seed=4)
     big.t[::5] *= 3.0                       # mostly out of the window
     i1 = np.asarray(big.i1).copy()
