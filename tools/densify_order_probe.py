@@ -52,6 +52,11 @@ for k, v in feat.items():
 orders["b2 + 0.05 sites, descending"] = np.argsort(-(feat["sites with >= 2 4-neighbours missing"] + 0.05 * feat["sites"]), kind="stable")
 for wgt in (2, 4, 8):
     orders[f"b1 + {wgt} b3, descending"] = np.argsort(-(feat["sites with a 4-neighbour missing"] + wgt * feat["sites with >= 5 of 8 neighbours missing"]), kind="stable")
+srt = np.argsort(-feat["sites with >= 2 4-neighbours missing"], kind="stable")
+for mix in (128, 256):
+    head = np.empty(2 * mix, dtype=np.int64)
+    head[0::2], head[1::2] = srt[:mix], srt[::-1][:mix]
+    orders[f"b2 descending, the first {2 * mix} alternating with the {mix} cheapest"] = np.concatenate([head, srt[mix:N - mix]])
 orders["b3 + 0.02 sites, descending"] = np.argsort(-(feat["sites with >= 5 of 8 neighbours missing"] + 0.02 * feat["sites"]), kind="stable")
 res = {}
 for name, order in orders.items():
