@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256) void bev_cost_kernel(const uint32_t* __restric
 }
 
 __global__ __launch_bounds__(1024) void bev_order_kernel(const int32_t* __restrict__ cost, int n, int32_t* __restrict__ order) {
+    static_assert(ORDER_BINS == 1024, "one bin per thread of the one workgroup");
     __shared__ int bins[ORDER_BINS];
     __shared__ int cmax;
     const int tid = threadIdx.x;
