@@ -57,6 +57,12 @@ for mix in (128, 256):
     head = np.empty(2 * mix, dtype=np.int64)
     head[0::2], head[1::2] = srt[:mix], srt[::-1][:mix]
     orders[f"b2 descending, the first {2 * mix} alternating with the {mix} cheapest"] = np.concatenate([head, srt[mix:N - mix]])
+for mix in (256,):   # the first round: the costliest alternating with MEDIAN renders (phases out of step from the start; the cheapest stay for the tail)
+    mid = srt[N // 2: N // 2 + mix]
+    head = np.empty(2 * mix, dtype=np.int64)
+    head[0::2], head[1::2] = srt[:mix], mid
+    rest = np.concatenate([srt[mix:N // 2], srt[N // 2 + mix:]])
+    orders[f"b2 descending, the first {2 * mix} alternating with {mix} median ones"] = np.concatenate([head, rest])
 orders["b3 + 0.02 sites, descending"] = np.argsort(-(feat["sites with >= 5 of 8 neighbours missing"] + 0.02 * feat["sites"]), kind="stable")
 res = {}
 for name, order in orders.items():
