@@ -315,41 +315,17 @@ static int ensure_star_table() {
 // ---- longest renders first (r5).  A launch of n renders is n / 512 rounds of resident workgroups, dispatched in the order of their
 // ids; renders differ in cost, and the launch ends with a tail in which CUs run dry behind the last, arbitrary renders.  With the
 // costly renders dispatched first the tail is made of cheap ones: densify -4 ... -5 % on every synthetic scene (box 14.04 -> 13.32 ms
-// per 4096, cluttered 19.24 -> 18.43, noisy 20.12 -> 19.64; tools/densify_order_probe.py), identical images -- renders are independent.
-// The cost estimate is a count the splat's occupancy bitmap gives for 32 KB of reads per render: sites with two or more of their four
+// per 4096, cluttered 19.24 -> 18.43, noisy 20.12 -> 19.64 with the order made on the host; tools/densify_order_probe.py), identical images -- renders are independent.
+// The cost estimate is a count the splat makes from a tile's occupancy words while they are in its LDS (bev_splat.h: emit_tile): sites with two or more of their four
 // neighbours missing (outline and isolated sites: the ones whose walks are long; the plain site or point count does not predict the
 // cluttered / noisy scenes, and of five such counts this one was good on all three scenes).
-// bev_cost_kernel: one workgroup per render -> cost[rid]; bev_order_kernel: ONE workgroup, counting sort by cost, descending, into
+// bev_order_kernel: ONE workgroup, counting sort by cost[] (summed by the splat's tiles with one atomic each), descending, into
 // order[] (ties in any order: the atomics of the scatter decide, nothing observable depends on it).
 constexpr int DENSIFY_ORDERED = 256;      // DensifyCfg::out_flags, set by bev_stage only: order[] is valid
 constexpr int ORDER_BINS = 1024;
 constexpr int ORDER_MIN_RENDERS = 1025;   // more than two rounds of the 512 resident workgroups.  Measured (tools/densify_order_threshold.py, costly
                                           // first against as given): 1536 ... 4096 renders -2.2 ... -6.9 % on the box and the noisy scene; at 640 / 768 /
                                           // 1024 renders -7 ... +4 % with either sign (1024 = exactly two rounds: +3.5 % box, config 5's launches +5 %)
-
-__global__ __launch_bounds__(256) void bev_cost_kernel(const uint32_t* __restrict__ bitmaps_all, int ntiles, int32_t* __restrict__ cost) {
-    const int rid = blockIdx.x, tid = threadIdx.x;
-    const uint4* bm_occ = reinterpret_cast<const uint4*>(bitmaps_all + (size_t)rid * 2 * ntiles * TILE_H * TILE_WORDS);
-    int cnt = 0;
-    for (int i = tid; i < ntiles * TILE_H; i += 256) {
-        const int r = i % TILE_H;
-        const uint4 o = bm_occ[i];
-        const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);        // rows and columns beyond the tile: taken as present
-        const uint4 a = r > 0 ? bm_occ[i - 1] : ones, b = r < TILE_H - 1 ? bm_occ[i + 1] : ones;
-        const uint32_t w[4] = {o.x, o.y, o.z, o.w}, up[4] = {a.x, a.y, a.z, a.w}, dn[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t R = (w[k] >> 1) | (k < 3 ? w[k + 1] << 31 : 0x80000000u), L = (w[k] << 1) | (k > 0 ? w[k - 1] >> 31 : 1u);
-            const uint32_t three = (L & R & (up[k] | dn[k])) | (up[k] & dn[k] & (L | R));   // at least three of the four neighbours are sites
-            cnt += __popc(w[k] & ~three);
-        }
-    }
-    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
-    __shared__ int part[4];
-    if ((tid & 63) == 0) part[tid >> 6] = cnt;
-    __syncthreads();
-    if (tid == 0) cost[rid] = part[0] + part[1] + part[2] + part[3];
-}
 
 __global__ __launch_bounds__(1024) void bev_order_kernel(const int32_t* __restrict__ cost, int n, int32_t* __restrict__ order) {
     static_assert(ORDER_BINS == 1024, "one bin per thread of the one workgroup");
@@ -1096,6 +1072,11 @@ int salve_bev_pano_index_build(const salve_bev_config_t* cfg, const uint16_t* pa
     return SALVE_OK;
 }
 
+// does a launch of n renders run its densify stage in cost order?  (both stages ask: the scatter sums the costs, the densify sorts them)
+static bool orders_renders(const DevCfg& d, int n, size_t npx) {
+    return !(d.out_flags & 4) && n >= ORDER_MIN_RENDERS && (size_t)2 * n * sizeof(int32_t) <= npx * sizeof(uint32_t);
+}
+
 static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* pano_rgb, const uint16_t* pano_depth,
                      int32_t n_panos, const double* sphere, const void* pano_index, const salve_bev_hyp_t* hyps, int32_t n, uint32_t* out_bev,
                      int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask, int32_t* dbg_stats, int32_t* in_window,
@@ -1123,6 +1104,9 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         const long long n_wg = (long long)((n + 7) / 8 * 8) * tiles_x * tiles_y;
         if (n_wg > 0x7FFFFFFFll) { salve_fail("too many renders for one splat launch"); return SALVE_ERR_BAD_ARG; }
         if (in_window) SALVE_HIP_CHECK(hipMemsetAsync(in_window, 0, (size_t)n * sizeof(int32_t), s));
+        // the renders' cost estimates for the densify stage's dispatch order: [cost n][order n] in the key image of the workspace
+        int32_t* cost = orders_renders(d, n, npx) ? reinterpret_cast<int32_t*>(ws.keys) : nullptr;
+        if (cost) SALVE_HIP_CHECK(hipMemsetAsync(cost, 0, (size_t)n * sizeof(int32_t), s));
         if (dbg_img_xy) SALVE_HIP_CHECK(hipMemsetAsync(dbg_img_xy, 0xFF, (size_t)n * d.npts * 2 * sizeof(int16_t), s));   // (-1, -1): cropped / pruned
         static std::mutex mu;
         static size_t attr[2][64] = {{0}};
@@ -1133,12 +1117,12 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
             if (st != SALVE_OK) return st;
             hipLaunchKernelGGL((bev_splat_kernel<true>), dim3((unsigned)n_wg), dim3(SPLAT_THREADS), sizeof(SplatLds), s, d, pg, pano_rgb, pano_depth,
                                sphere, hyps, boxes, ranges, ranges + 2 * n_panos, out_bev, ws.bitmaps, in_window, dbg_img_xy, reinterpret_cast<unsigned long long*>(dbg_keys), status, n,
-                               n_panos, tiles_x, tiles_y);
+                               n_panos, tiles_x, tiles_y, cost);
         } else {
             const int st = ensure_lds(bev_splat_kernel<false>, sizeof(SplatLds), attr[0], mu);
             if (st != SALVE_OK) return st;
             hipLaunchKernelGGL((bev_splat_kernel<false>), dim3((unsigned)n_wg), dim3(SPLAT_THREADS), sizeof(SplatLds), s, d, pg, pano_rgb, pano_depth,
-                               sphere, hyps, boxes, ranges, ranges + 2 * n_panos, out_bev, ws.bitmaps, in_window, nullptr, nullptr, status, n, n_panos, tiles_x, tiles_y);
+                               sphere, hyps, boxes, ranges, ranges + 2 * n_panos, out_bev, ws.bitmaps, in_window, nullptr, nullptr, status, n, n_panos, tiles_x, tiles_y, cost);
         }
         SALVE_HIP_CHECK(hipGetLastError());
     }
@@ -1148,11 +1132,10 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
         static std::mutex mu;
         static size_t attr[2][64] = {{0}};
         DensifyCfg dc = {d.H, d.W, d.wpr, d.mask_half, d.out_flags & 255, d.dbg_flags};
-        // the order of the renders inside the launch (bev_cost_kernel / bev_order_kernel above); its two int32 arrays live in the
-        // workspace's key image, which only the single-render utility paths use
-        if (!(d.out_flags & 4) && n >= ORDER_MIN_RENDERS && (size_t)2 * n * sizeof(int32_t) <= npx * sizeof(uint32_t)) {
-            int32_t* cost = reinterpret_cast<int32_t*>(ws.keys);
-            hipLaunchKernelGGL(bev_cost_kernel, dim3(n), dim3(256), 0, s, ws.bitmaps, tiles_x * tiles_y, cost);
+        // the order of the renders inside the launch (bev_order_kernel above); its two int32 arrays live in the workspace's key
+        // image, which only the single-render utility paths use
+        if (orders_renders(d, n, npx)) {
+            int32_t* cost = reinterpret_cast<int32_t*>(ws.keys);   // summed by the scatter stage of the same renders
             hipLaunchKernelGGL(bev_order_kernel, dim3(1), dim3(1024), 0, s, cost, n, cost + n);
             SALVE_HIP_CHECK(hipGetLastError());
             dc.out_flags |= DENSIFY_ORDERED;

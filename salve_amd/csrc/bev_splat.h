@@ -117,7 +117,7 @@ struct SplatLds {
 template <bool DEV>
 __device__ __forceinline__ void emit_tile(const DevCfg& c, SplatLds& s, const uint8_t* __restrict__ colours, uint32_t* __restrict__ bev,
                                           uint32_t* __restrict__ bitmaps, unsigned long long* __restrict__ dbg_keys, int t, int ntiles,
-                                          int tx0, int ty0) {
+                                          int tx0, int ty0, int32_t* __restrict__ cost = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = SPLAT_THREADS >> 6;
     const int flip = (c.out_flags & 1) ? -1 : c.H - 1;
     // EMIT_ROWS rows x two 64-pixel segments per step: all keys, then all colour gathers (a fifth of the pixels hold a winner),
@@ -161,6 +161,23 @@ __device__ __forceinline__ void emit_tile(const DevCfg& c, SplatLds& s, const ui
         const int which = tid / TILE_H, row = tid % TILE_H;
         const uint4 v = *reinterpret_cast<const uint4*>(&s.bm[which][row][0]);
         *reinterpret_cast<uint4*>(bitmaps + (((size_t)which * ntiles + t) * TILE_H + row) * TILE_WORDS) = v;
+        // The render's cost estimate for the densify stage's dispatch order (bev_render.hip: bev_order_kernel -- the costly renders
+        // of a launch first): the number of sites with two or more of their four neighbours missing, counted tile by tile from the
+        // occupancy words that are in LDS right here (rows and columns beyond the tile count as present).
+        static_assert(TILE_H % 64 == 0, "whole wavefronts count the occupancy rows");
+        if (cost && which == 0) {   // (wave-uniform: TILE_H is a multiple of 64)
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t up = row > 0 ? s.bm[0][row - 1][k] : ~0u, dn = row < TILE_H - 1 ? s.bm[0][row + 1][k] : ~0u;
+                const uint32_t R = (w[k] >> 1) | (k < 3 ? w[k + 1] << 31 : 0x80000000u), L = (w[k] << 1) | (k > 0 ? w[k - 1] >> 31 : 1u);
+                const uint32_t three = (L & R & (up | dn)) | (up & dn & (L | R));   // at least three of the four neighbours are sites
+                cnt += __popc(w[k] & ~three);
+            }
+            for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+            if (lane == 0 && cnt) atomicAdd(cost, cnt);
+        }
     }
 }
 
@@ -169,7 +186,8 @@ __global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_
     DevCfg c, PanoGrid pg, const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, const double* __restrict__ sphere,
     const salve_bev_hyp_t* __restrict__ hyps, const float4* __restrict__ boxes, const int* __restrict__ range_lo, const int* __restrict__ range_hi,
     uint32_t* __restrict__ bev_all, uint32_t* __restrict__ bitmaps_all, int32_t* __restrict__ in_window, int16_t* __restrict__ dbg_xy_arg,
-    unsigned long long* __restrict__ dbg_keys_arg, int32_t* __restrict__ status, int n_renders, int n_panos, int tiles_x, int tiles_y) {
+    unsigned long long* __restrict__ dbg_keys_arg, int32_t* __restrict__ status, int n_renders, int n_panos, int tiles_x, int tiles_y,
+    int32_t* __restrict__ cost) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SplatLds& s = *reinterpret_cast<SplatLds*>(smem);
     int16_t* const dbg_xy = DEV ? dbg_xy_arg : nullptr;
@@ -303,7 +321,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_
     if (tid == 0 && in_window && s.in_window) atomicAdd(in_window + rid, s.in_window);
     const uint8_t* colours = rgb + ((size_t)h.pano_idx * c.pano_h + c.crop_rows) * c.pano_w * 3;
     emit_tile<DEV>(c, s, colours, bev_all + (size_t)rid * c.H * c.W, bitmaps_all + (size_t)rid * 2 * ntiles * TILE_H * TILE_WORDS,
-                   dbg_keys ? dbg_keys + (size_t)rid * c.H * c.W : nullptr, t, ntiles, tx0, ty0);
+                   dbg_keys ? dbg_keys + (size_t)rid * c.H * c.W : nullptr, t, ntiles, tx0, ty0, cost ? cost + rid : nullptr);
 }
 
 // Utility paths (one render): key image in memory -> the same emission.

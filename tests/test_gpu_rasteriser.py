@@ -464,8 +464,8 @@ def test_scatter_then_densify_equals_render_and_the_sparse_image_is_the_oracles(
 
 
 def test_costly_renders_first_is_the_same_images(setup):
-    """From 1025 renders per launch on, the densify stage dispatches the costly renders first (bev_cost_kernel / bev_order_kernel:
-    a count from the occupancy bitmaps, a counting sort, an index array behind the bitmaps in the workspace; out_flags bit 4 keeps
+    """From 1025 renders per launch on, the densify stage dispatches the costly renders first (a count the splat makes from
+    its occupancy bitmaps, bev_order_kernel's counting sort, an index array behind the bitmaps in the workspace; out_flags bit 4 keeps
     the given order).  Renders are independent: both orders give the same images, image for image -- over a launch that mixes cheap
     renders (clouds half out of the window, empty renders of a panorama that is not in the batch) with full ones."""
     ras, panos, d_rgb, d_depth, hyp = setup
