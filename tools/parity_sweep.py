@@ -1,5 +1,6 @@
 """One-off wide parity sweep (GPU box): N random hypotheses x {floor, ceiling} over several panoramas, final BEV images
-bit for bit against the oracle's exact mode, oracle renders in a process pool.  python tools/parity_sweep.py [N] [procs] [scene] [seed]"""
+bit for bit against the oracle's exact mode, oracle renders in a process pool.  python tools/parity_sweep.py [N] [procs] [scene] [seed] [HxW]
+(HxW: the panoramas' size, default 512x1024; 1024x2048 is BASELINE config 5's -- four times the points per render, keep N <= 1536)"""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -10,8 +11,8 @@ import numpy as np
 def oracle_one(args):
     from oracle import bev_oracle as bo
     from salve_amd import synthetic
-    pi, surface, R, t, scene = args
-    rgb, depth = synthetic.make_pano(pi, scene=scene)
+    pi, surface, R, t, scene, hw = args
+    rgb, depth = synthetic.make_pano(pi, hw[0], hw[1], scene=scene)
     a = bo.xyzrgb_from_arrays(depth, rgb, bo.floor_ceiling_z_range(surface))
     a, _ = bo.pose_pair(a, a[:1], R, t)
     res = bo.render_bev_image(a, mode="exact")
@@ -26,18 +27,19 @@ if __name__ == "__main__":
     procs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     scene = sys.argv[3] if len(sys.argv) > 3 else "box"
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else 123
+    hw = tuple(int(v) for v in sys.argv[5].lower().split("x")) if len(sys.argv) > 5 else (512, 1024)
     P = 6
     hyp = synthetic.make_hypotheses(N, P, seed=seed)
     hyp.t[::7] *= 2.0     # some clouds half out of the window
     surf = np.arange(N) % 2
-    jobs = [(int(hyp.i1[j]), "floor" if surf[j] == 0 else "ceiling", hyp.R[j], hyp.t[j], scene) for j in range(N)]
+    jobs = [(int(hyp.i1[j]), "floor" if surf[j] == 0 else "ceiling", hyp.R[j], hyp.t[j], scene, hw) for j in range(N)]
     t0 = time.time()
     with mp.get_context("spawn").Pool(procs) as pool:
         ref = pool.map(oracle_one, jobs, chunksize=2)
     print(f"oracle: {time.time() - t0:.0f} s for {N} renders", flush=True)
     dev = torch.device("cuda:0")
-    ras = BevRasteriser(dev)
-    panos = [synthetic.make_pano(i, scene=scene) for i in range(P)]
+    ras = BevRasteriser(dev, pano_hw=hw)
+    panos = [synthetic.make_pano(i, hw[0], hw[1], scene=scene) for i in range(P)]
     d_rgb, d_depth = ras.upload_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     h = pack_hypotheses(hyp.i1, surf, hyp.R, hyp.t, np.ones(N))
     bad = 0
@@ -51,5 +53,5 @@ if __name__ == "__main__":
                 print("MISMATCH rep", rep, "render", j, jobs[j][:2], int((got[j] != exp).any(-1).sum()), "pixels", flush=True)
     from salve_amd import status
     status.check(dev, "parity_sweep")
-    print(f"scene {scene}, seed {seed}: renders compared:", 3 * N, "mismatches:", bad)
+    print(f"scene {scene}, panoramas {hw[1]}x{hw[0]}, seed {seed}: renders compared:", 3 * N, "mismatches:", bad)
     sys.exit(1 if bad else 0)
