@@ -156,3 +156,20 @@ def test_sites_left_out_of_the_list_own_unit_triangles_only(lib):
     bad, n_out, _ = left_out(lib, sites, 501, 501)
     print(f"real render: {n_out} of {len(sites)} sites need no walk ({100.0 * n_out / len(sites):.1f} %)")
     assert bad == 0 and n_out > 0.45 * len(sites)
+
+
+def test_the_walk_counter_tool_builds_and_reproduces_the_triangulation(tmp_path):
+    """tools/host/walk_counters.cpp (development: the general walk's counters with the kernel's E2 schedule simulated) compiles against
+    the kernel's headers as they are, and its simulated schedule -- eight wavefronts, runs of eight, delayed cache visibility -- emits
+    the oracle's triangles for a realistic site set."""
+    exe = tmp_path / "walk_counters"
+    subprocess.run(["g++", "-O2", "-o", str(exe), str(ROOT / "tools" / "host" / "walk_counters.cpp")], check=True)
+    hyp = synthetic.make_hypotheses(16, 2, seed=0)
+    p0 = synthetic.make_pano(0)
+    a = bo.xyzrgb_from_arrays(p0[1], p0[0], bo.floor_ceiling_z_range("floor"))
+    a, _ = bo.pose_pair(a, a[:1], hyp.R[3], hyp.t[3])
+    res = bo.render_bev_image(a, mode="exact")
+    sites = tmp_path / "sites.bin"
+    res["site_xy_sorted"].astype(np.int32).tofile(sites)
+    out = subprocess.run([str(exe), str(sites)], check=True, capture_output=True, text=True).stdout
+    assert f"sites {len(res['site_xy_sorted'])} triangles {len(res['tri'])} " in out, out
