@@ -10,8 +10,16 @@ A step = one pass of the fused render+verify path over the rank's shard of the h
 (BASELINE.json configs[2]: 4096 hypotheses over 64 synthetic 1024x512 panoramas, rasteriser + ResNet-50 fp16,
 per GPU -> weak scaling).  Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
-BASELINE.json configs[4] on one GPU (same JSON schema, `config.workload` names it):
-    python bench.py --pano-hw 1024x2048 --surfaces floor,ceiling --layers 152 --hyps 1024 --panos 16 --chunk 512
+At N = 1 the same JSON line also carries, all measured OUTSIDE the timed region:
+  * `roofline.hbm_copy_gbs_measured` -- a 4 GB device copy on this box (SURVEY 8d: "confirm with a copy microbenchmark on the box");
+  * `roofline_verifier.gemm_*` -- a plain fp16 GEMM (fp32 accumulation, random data, torch.matmul = hipBLASLt: a MEASUREMENT REFERENCE,
+    never product) at the three 3 x 3 shapes of the forward + one square shape, each with board power and shader clock: what the matrix
+    pipes of THIS box sustain at its power cap, beside what conv8_kernel gets;
+  * `config5` -- BASELINE.json configs[4] (2048 x 1024 panoramas, floor + ceiling, ResNet-152 12-channel), 3 timed steps at the launch
+    size the pipeline picks (pipeline.pick_launch).
+BASELINE.json configs[4] alone (same JSON schema, `config.workload` names it):
+    python bench.py --pano-hw 1024x2048 --surfaces floor,ceiling --layers 152 --panos 16
+`--chunk N` fixes the hypotheses per launch (default: chosen by the pipeline from the free HBM -- the whole shard when it fits).
 `--force-dist` runs `init_process_group("nccl")` and the logits all-gather even with a single rank (RCCL on one GPU).
 """
 
@@ -92,7 +100,7 @@ def _hwmon_of(device_index: int):
     return None
 
 
-def power_probe(fn, seconds: float = 3.0, device_index: int = 0):
+def power_probe(fn, seconds: float = 3.0, device_index: int = 0, batch: int = 4, want_rate: bool = False):
     """Board power and shader clock while `fn` (one verifier forward) runs in a sustained loop, OUTSIDE the timed region: the forward runs
     at the board's power limit, so the clock the matrix pipes actually get -- not the 2.4 GHz the 2.5 PFLOP/s peak
     assumes -- is part of what the roofline fraction means.  Read from the GPU's hwmon files in sysfs by a thread while the loop runs (no
@@ -100,11 +108,13 @@ def power_probe(fn, seconds: float = 3.0, device_index: int = 0):
     import threading
 
     hw = _hwmon_of(device_index)
-    if hw is None:
+    if hw is None and not want_rate:
         return None
     samples, stop = [], threading.Event()
 
     def sampler():
+        if hw is None:
+            return
         time.sleep(1.0)   # let the clocks settle under load
         while not stop.is_set():
             try:
@@ -117,21 +127,161 @@ def power_probe(fn, seconds: float = 3.0, device_index: int = 0):
 
     th = threading.Thread(target=sampler, daemon=True)
     th.start()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
+    calls, gpu_ms = 0, 0.0
     while time.perf_counter() - t0 < seconds:
-        for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(batch):
             fn()
+        e1.record()
         torch.cuda.synchronize()
+        if time.perf_counter() - t0 > 1.0 or seconds <= 1.0:   # rate: only once the clocks have settled under load
+            calls += batch
+            gpu_ms += e0.elapsed_time(e1)
     stop.set()
     th.join(timeout=5)
+    rate = {"ms_per_call": (gpu_ms / calls) if calls else None, "calls_timed": calls}
     if not samples:
-        return None
+        return rate if want_rate else None
     try:
         cap = int(open(hw + "/power1_cap").read()) / 1e6
     except Exception:
         cap = None
     return {"power_w": round(float(np.mean([a for a, _ in samples])), 1), "sclk_mhz": round(float(np.mean([b for _, b in samples])), 1),
-            "power_cap_w": cap, "samples": len(samples)}
+            "power_cap_w": cap, "samples": len(samples), **rate}
+
+
+# The three 3 x 3 convolutions of the ResNet-50 forward as GEMMs (reference shapes: salve/models/resnet_factory.py:26-44 = torchvision's
+# Bottleneck widths; batch 4096 x output pixels, C_out, 9 C_in) and one square shape whose operands' HBM time is far below its matrix time.
+GEMM_SHAPES = [("l3_3x3_256to256_at14", 4096 * 196, 256, 2304), ("l2_3x3_128to128_at28", 4096 * 784, 128, 1152),
+               ("l4_3x3_512to512_at7", 4096 * 49, 512, 4608), ("square_8192", 8192, 8192, 8192)]
+
+
+def gemm_probe(dev, device_index: int, seconds: float = 2.5):
+    """What a plain fp16 GEMM with fp32 accumulation sustains on THIS box at its power cap, on random data (the power an MFMA draws
+    depends on the bits it multiplies): torch.matmul (hipBLASLt) -- a measurement reference beside the product's convolution kernels,
+    never part of the product path.  A[M, K] x W[N, K]^T, the layout of an im2col'd activation against packed weights.  An explicit
+    A matrix is nine times the bytes the implicit GEMM reads, so the shapes with small N K / (N + K) are HBM-bound AS GEMMs
+    (`flop_per_byte` x the copy rate is their cap); the square shape and the N = 512 shape are not."""
+    out = {}
+    for name, M, N, K in GEMM_SHAPES:
+        try:
+            a = torch.randn((M, K), dtype=torch.float16, device=dev)
+            w = torch.randn((N, K), dtype=torch.float16, device=dev)
+            c = torch.empty((M, N), dtype=torch.float16, device=dev)
+            fn = lambda: torch.matmul(a, w.t(), out=c)
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            r = power_probe(fn, seconds=seconds, device_index=device_index, batch=8, want_rate=True)
+            flop = 2.0 * M * N * K
+            e = {"m": M, "n": N, "k": K, "tflops": None if not r or not r.get("ms_per_call") else round(flop / r["ms_per_call"] / 1e9, 1),
+                 "flop_per_byte": round(flop / (2.0 * (M * K + N * K + M * N)), 1)}
+            if r:
+                e.update({k: r[k] for k in ("power_w", "sclk_mhz") if k in r})
+            out[name] = e
+            del a, w, c
+        except Exception as ex:   # a box whose free memory or BLAS build cannot run a shape reports that, the benchmark line stays valid
+            out[name] = {"m": M, "n": N, "k": K, "tflops": None, "error": str(ex)[:120]}
+        torch.cuda.empty_cache()
+    return out
+
+
+def copy_probe(dev, gbytes: float = 4.0, iters: int = 20):
+    """HBM copy rate of this box: a float4 device-to-device copy of 4 GB, bytes read + bytes written per second.  The kernel is the
+    measurement helper of tests/native (a grid-stride float4 copy, 8 workgroups per CU; not part of the product library); where that
+    library is not built, torch's `copy_` (the runtime's blit) is timed instead and the line says so.  Returns (GB/s, what ran)."""
+    import ctypes
+
+    n = int(gbytes * (1 << 30)) // 16
+    src = torch.empty((n, 4), dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    fn, what = (lambda: dst.copy_(src)), "torch copy_ (runtime blit)"
+    helper = ROOT / "tests" / "native" / "libsalve_testhelp.so"
+    if helper.exists():
+        try:
+            lib = ctypes.CDLL(str(helper))
+            lib.salve_debug_copy16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int32, ctypes.c_void_p]
+            lib.salve_debug_copy16.restype = ctypes.c_int
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            stream = lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+            def fn():
+                if lib.salve_debug_copy16(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), n, 8 * cus, stream()) != 0:
+                    raise RuntimeError("salve_debug_copy16 failed")
+            what = "float4 grid-stride copy kernel (tests/native/testhelp.hip)"
+        except (OSError, AttributeError):
+            pass
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    ok = bool(torch.equal(dst[:1024], src[:1024]) and torch.equal(dst[-1024:], src[-1024:]))
+    del src, dst
+    torch.cuda.empty_cache()
+    return (round(2.0 * n * 16 / (ms * 1e-3) / 1e9, 1) if ok else None), what
+
+
+def make_panos(n: int, pano_h: int, pano_w: int, scene: str):
+    """The synthetic panoramas of a run, generated by a few host threads (numpy releases the GIL; a 2048 x 1024 panorama takes 2 s)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from salve_amd import synthetic
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, n))) as pool:
+        return list(pool.map(lambda i: synthetic.make_pano(i, pano_h, pano_w, scene=scene), range(n)))
+
+
+def config5_line(dev, hyps: int = 4096, panos: int = 16, steps: int = 3, warmup: int = 1):
+    """BASELINE.json configs[4] on this GPU, after the main region: 2048 x 1024 panoramas, floor + ceiling, ResNet-152 with the 12-channel
+    early fusion (the reference's released models: salve/configs/*.yaml, num_layers 152), `hyps` hypotheses at the launch size the pipeline
+    picks, `steps` timed passes between device synchronisations."""
+    from salve_amd import synthetic
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from salve_amd.pipeline import RenderVerifyPipeline
+
+    H, W, S = 1024, 2048, 2
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(152, False, 2, SimpleNamespace(modalities=["ceiling_rgb_texture", "floor_rgb_texture"])).eval()
+    synthetic.trained_looking_batchnorm(model)
+    pipe = RenderVerifyPipeline(model, dev, pano_hw=(H, W), chunk=None, overlap=False, streams=1, n_hypotheses=hyps)
+    ps = make_panos(panos, H, W, "box")
+    pipe.load_panos(np.stack([p[0] for p in ps]), np.stack([p[1] for p in ps]))
+    prepared = pipe.prepare(synthetic.make_hypotheses(hyps, panos, seed=0))
+    logits = torch.empty((hyps, 2), dtype=torch.float32, device=dev)
+    for _ in range(warmup):
+        pipe.score(prepared, out=logits)
+    ev, vev = [], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.score(prepared, out=logits, timers=ev, vtimers=vev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pipe.check("bench.py config 5")
+    assert bool(torch.isfinite(logits).all())
+    launch = min(pipe.chunk, hyps)
+    renders = launch * S
+    mean_ms = lambda tag: float(np.mean([a.elapsed_time(b) for a, b, r, t in ev if t == tag and r == renders]))
+    scat_ms, dens_ms = mean_ms("scatter"), mean_ms("densify")
+    ver_ms = float(np.mean([a.elapsed_time(b) for a, b, r in vev if r == launch]))
+    gflop = GFLOP_PER_SAMPLE[(152, 12)]
+    achieved = renders * bytes_per_render(H, W) / ((scat_ms + dens_ms) * 1e-3) / 1e9
+    tflops = launch * gflop / ver_ms
+    return {"workload": f"BASELINE config 5: {hyps} hypotheses over {panos} synthetic {W}x{H} panoramas (box scene), floor + ceiling, HIP BEV rasteriser + "
+                        f"ResNet-152 (12-ch early fusion) fp16 MFMA verifier", "value": round(hyps * steps / dt, 2), "unit": "hypotheses/s",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "launch": launch, "renders_per_launch": renders,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "scatter_ms": round(scat_ms, 3), "densify_ms": round(dens_ms, 3), "algorithmic_bytes_per_render": bytes_per_render(H, W)},
+            "roofline_verifier": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tflops / MFMA_PEAK_TFLOPS, 5), "launch_ms": round(ver_ms, 3), "gflop_per_sample": gflop}}
 
 
 def _cores() -> int:
@@ -241,8 +391,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hyps", type=int, default=4096, help="hypotheses per GPU")
     ap.add_argument("--panos", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=4096, help="hypotheses per render / verify launch (the whole shard: launches of 4096 renders /\n"
-                    "samples run 10 % faster per unit than launches of 1024; the rasteriser of pass k + 1 runs under the verifier of pass k)")
+    ap.add_argument("--chunk", type=int, default=0, help="hypotheses per render / verify launch; 0 (default): the pipeline picks the largest launch that\n"
+                    "fits half of the free HBM -- the whole shard here (launches of 4096 run 10 %% faster per unit than launches of 1024)")
     ap.add_argument("--no-overlap", action="store_true", help="same as --streams 1")
     ap.add_argument("--streams", type=int, default=1, help="1: one HIP stream (default: with whole-shard launches the overlapped schedules gain\n"
                     "1 % -- the kernels then share the CUs and each runs longer -- and blur the per-kernel times the rooflines are computed from);\n"
@@ -254,7 +404,14 @@ def main() -> None:
     ap.add_argument("--scene", default="box", help="synthetic scene: box (SURVEY 8d) | cluttered (occluding boxes + door opening) | noisy (cluttered + network-like depth errors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 3 s loop of verifier forwards during which board power and shader clock are read from sysfs")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the GEMM and copy microbenchmarks (measured roofs of this box)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 sub-measurement")
     args = ap.parse_args()
+
+    # before anything starts a rank or touches a GPU: are there that many devices?  (device_count() does not initialise the GPU)
+    have = torch.cuda.device_count()
+    if args.gpus < 1 or args.gpus > have:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); nothing was launched")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(_self_launch(args, sys.argv[1:]))
@@ -286,8 +443,9 @@ def main() -> None:
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(args.layers, False, 2, SimpleNamespace(modalities=modalities)).eval()
     synthetic.trained_looking_batchnorm(model)  # random-init weights of the named architecture; seeded trained-looking statistics
-    pipe = RenderVerifyPipeline(model, dev, pano_hw=(pano_h, pano_w), chunk=args.chunk, overlap=(args.streams > 1 and not args.no_overlap), streams=args.streams)
-    panos = [synthetic.make_pano(i, pano_h, pano_w, scene=args.scene) for i in range(args.panos)]
+    pipe = RenderVerifyPipeline(model, dev, pano_hw=(pano_h, pano_w), chunk=(args.chunk or None), overlap=(args.streams > 1 and not args.no_overlap),
+                                streams=args.streams, n_hypotheses=args.hyps)
+    panos = make_panos(args.panos, pano_h, pano_w, args.scene)
     pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     # weak scaling: every rank scores its own block of `hyps` hypotheses out of a table of world * hyps
     n_total = args.hyps * world
@@ -321,7 +479,7 @@ def main() -> None:
 
     if rank == 0:
         value = n_total * args.steps / dt
-        full_n = min(args.chunk, len(table))           # hypotheses per launch
+        full_n = min(pipe.chunk, len(table))           # hypotheses per launch
         renders = full_n * S                           # renders per rasteriser launch
         bpr = bytes_per_render(pano_h, pano_w)
         mean_ms = lambda tag: float(np.mean([a.elapsed_time(b) for a, b, r, t in ev if t == tag and r == renders]))
@@ -347,7 +505,7 @@ def main() -> None:
                                    f"({args.scene} scene), {' + '.join(surfaces)} surface{'s' if S > 1 else ''}, HIP BEV rasteriser + ResNet-{args.layers} "
                                    f"({6 * S}-ch early fusion) fp16 MFMA verifier",
                        "shape": shape, "hypotheses_per_gpu": args.hyps, "panos": args.panos, "renders_per_hypothesis": S,
-                       "cached_identity_renders": args.panos * S, "chunk": args.chunk, "hip_streams": 1 if args.no_overlap else args.streams,
+                       "cached_identity_renders": args.panos * S, "chunk": pipe.chunk, "chunk_chosen_by": "--chunk" if args.chunk else "pipeline.pick_launch", "hip_streams": 1 if args.no_overlap else args.streams,
                        "parallelism": f"hypothesis-shard x{world}", "rccl": bool(use_dist)},
             # the rasteriser as a whole (splat + densify): SURVEY 8d's bytes per render x the renders of one launch /
             # the summed average durations of those launches (HIP events on the launching streams).  The pose-independent
@@ -381,6 +539,24 @@ def main() -> None:
                 out["roofline_verifier"].update({"power_w": probe["power_w"], "power_cap_w": probe["power_cap_w"], "sclk_mhz": probe["sclk_mhz"], "power_samples": probe["samples"],
                                                  "peak_at_sclk": round(MFMA_PEAK_TFLOPS * probe["sclk_mhz"] / 2400.0, 1),
                                                  "frac_at_sclk": round(tflops / (MFMA_PEAK_TFLOPS * probe["sclk_mhz"] / 2400.0), 5)})
+        if world == 1 and not (args.no_calibration and args.no_config5):
+            # everything below needs the memory, not the pipeline: release the main workload's buffers
+            del pipe, prepared, logits, allg, table
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_calibration:
+            gbs, what = copy_probe(dev)
+            out["roofline"].update({"hbm_copy_gbs_measured": gbs, "hbm_copy_kernel": what,
+                                    "frac_of_measured_copy": None if not gbs else round(achieved / gbs, 6)})
+            g = gemm_probe(dev, local_rank)
+            out["roofline_verifier"]["gemm_reference"] = g
+            conv_shapes = [v["tflops"] for k, v in g.items() if k != "square_8192" and v.get("tflops")]
+            best = max([v["tflops"] for v in g.values() if v.get("tflops")], default=None)
+            out["roofline_verifier"].update({"gemm_tflops_measured": best, "gemm_tflops_conv_shapes": conv_shapes,
+                                             "gemm_power_w": next((v.get("power_w") for v in g.values() if v.get("tflops") == best), None),
+                                             "gemm_sclk_mhz": next((v.get("sclk_mhz") for v in g.values() if v.get("tflops") == best), None),
+                                             "frac_of_measured_gemm": None if not best else round(tflops / best, 5)})
+        if world == 1 and not args.no_config5 and not config5 and args.scene == "box":
+            out["config5"] = config5_line(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

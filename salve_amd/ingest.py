@@ -171,9 +171,10 @@ def load_floor_hypotheses(hypotheses_save_root: str, building_id: str, floor_id:
 
 
 def score_floor(model, device, raw_dataset_dir: str, depth_save_root: str, hypotheses_save_root: str, bev_save_root: str,
-                building_id: str, floor_id: str, serialization_save_dir: str, batch_size: int = 64, chunk: int = 512):
+                building_id: str, floor_id: str, serialization_save_dir: str, batch_size: int = 64, chunk: Optional[int] = None):
     """Disk -> predictions for one floor without writing a tile: the fused counterpart of running
-    scripts/render_dataset_bev.py and then scripts/test.py on that floor."""
+    scripts/render_dataset_bev.py and then scripts/test.py on that floor.  chunk = hypotheses per launch; None: the pipeline picks the
+    largest launch that fits the free HBM (pipeline.pick_launch)."""
     from salve_amd import evaluate
     from salve_amd.pipeline import RenderVerifyPipeline
 
@@ -182,7 +183,7 @@ def score_floor(model, device, raw_dataset_dir: str, depth_save_root: str, hypot
         return None
     img_fpaths = floor_pano_fpaths(raw_dataset_dir, building_id)
     store = PanoStore(device).load(img_fpaths, depth_save_root, building_id, np.concatenate([hyps.i1, hyps.i2]))
-    pipe = RenderVerifyPipeline(model, device, pano_hw=store.pano_hw, chunk=chunk)
+    pipe = RenderVerifyPipeline(model, device, pano_hw=store.pano_hw, chunk=chunk, n_hypotheses=len(hyps))
     pipe.set_panos(store.rgb, store.depth)
     return evaluate.run_fused_epoch(pipe, hyps.table(store, img_fpaths), hyps.tile_names(bev_save_root, img_fpaths), hyps.label,
                                     serialization_save_dir, batch_size=batch_size)

@@ -62,9 +62,41 @@ def render_order(i1: np.ndarray, chunk: int) -> Tuple[np.ndarray, np.ndarray]:
     return order, rank
 
 
+def pick_launch(n_hypotheses: int, per_hypothesis_bytes: int, budget_bytes: int, surfaces: int = 1, granule_renders: int = 512) -> int:
+    """Hypotheses per render / verify launch, chosen instead of documented: the LARGEST launch the memory budget allows, because both
+    stages run faster per unit in large launches (a launch ends in a tail of partly filled rounds of resident workgroups: densify
+    4.7 us per render in launches of 4096 against 8.1 us at 1024; config 5: 18.5 k hypotheses/s at 512 per launch, 20.6 k at 1024,
+    22.0 k at 2048 -- DESIGN.md 6).  The whole shard in one launch if it fits; otherwise the shard is cut into the FEWEST launches that
+    fit, of equal size (no short last launch), rounded up to whole rounds of the 512 resident densify workgroups (`granule_renders`
+    renders = granule / surfaces hypotheses).  The costly-renders-first order of the densify stage pays from 1025 renders per launch
+    and costs at exactly two rounds (1024); the library switches it on only above that (bev_render.hip: ORDER_MIN_RENDERS), and this
+    chooser never cuts a shard that has more than 1024 renders into launches of 1024 or fewer unless memory forces it.
+    Pure host arithmetic (tests/test_host_logic.py)."""
+    n = int(n_hypotheses)
+    if n <= 0:
+        raise ValueError("n_hypotheses must be positive")
+    fit = int(budget_bytes) // max(1, int(per_hypothesis_bytes))
+    if fit <= 0:
+        raise RuntimeError(f"not even one hypothesis ({per_hypothesis_bytes} B) fits the launch budget of {budget_bytes} B")
+    if fit >= n:
+        return n
+    g = max(1, granule_renders // max(1, int(surfaces)))
+    launches = -(-n // fit)
+    chunk = -(-n // launches)                 # equal launches
+    chunk = -(-chunk // g) * g                # whole rounds of resident workgroups
+    while chunk > fit and chunk > g:          # rounding up must not leave the budget
+        chunk -= g
+    return max(1, min(chunk, fit))
+
+
 class RenderVerifyPipeline:
-    def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: int = 512,
-                 overlap: bool = True, streams: int = 3) -> None:
+    LAUNCH_HBM_FRACTION = 0.5   # of the HBM that is free when the pipeline is created: BEV + tile + rasteriser + activation workspaces of one launch
+
+    def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: Optional[int] = None,
+                 overlap: bool = True, streams: int = 3, n_hypotheses: Optional[int] = None) -> None:
+        """chunk: hypotheses per render / verify launch.  None (default): chosen by `pick_launch` from the HBM that is free now --
+        the whole shard of `n_hypotheses` rows in one launch if its workspaces fit LAUNCH_HBM_FRACTION of it (a shard of 4096
+        hypotheses needs 57 GB with one surface / ResNet-50, 80 GB with two / ResNet-152, of 288), else the fewest equal launches."""
         self.device = torch.device(device)
         # the status word is one per device: a bit an earlier, unchecked caller left behind must be reported as ITS failure,
         # not raised later by this pipeline's check() under the wrong name
@@ -74,13 +106,19 @@ class RenderVerifyPipeline:
         self.has_layout = "layout" in set(model.modalities)
         self.engine = model.compiled(self.device)
         self.ras = BevRasteriser(self.device, pano_hw=pano_hw)
-        self.chunk = chunk
         S = len(self.surfaces)
         Hb, Wb = self.ras.bev_hw
+        nbuf = 2 if overlap else 1
+        if chunk is None:
+            if n_hypotheses is None:
+                raise ValueError("RenderVerifyPipeline(chunk=None) chooses the launch size itself and needs n_hypotheses (rows of the shard)")
+            chunk = pick_launch(n_hypotheses, self.per_hypothesis_bytes(nbuf, 2 if (overlap and streams >= 3) else 1),
+                                int(torch.cuda.mem_get_info(self.device)[0] * self.LAUNCH_HBM_FRACTION), max(1, S))
+        self.chunk = int(chunk)
         # overlap=True: two sets of chunk buffers -- the rasteriser (VALU / LDS-latency bound) fills one on its own HIP
         # stream while the verifier (MFMA / HBM bound) consumes the other, so the tail of one launch runs under the other
         # kernel.  (Requires the library to be built without SLP-packed fp32: DESIGN.md section 8.)
-        self.nbuf = 2 if overlap else 1
+        self.nbuf = nbuf
         self.bevs = [torch.empty((chunk * S, Hb, Wb), dtype=torch.int32, device=self.device) for _ in range(self.nbuf)]
         # tiles: fp16 NHWC, pad channels (never written) stay zero
         self.tile_bufs = [torch.zeros((chunk, self.ras.crop, self.ras.crop, self.engine.in_channels), dtype=torch.float16,
@@ -100,6 +138,21 @@ class RenderVerifyPipeline:
         self._consumed = [None] * self.nbuf
         self._panos_ready = None
         self.last_chunk_buffer = {}   # chunk index of the last score() call -> buffer set (self.bevs / self.tile_bufs) it used
+
+    def per_hypothesis_bytes(self, nbuf: int = 1, ws_slots: int = 1) -> int:
+        """Device bytes one hypothesis of a launch needs: its BEV images and early-fusion tile (per buffer set), the rasteriser's
+        workspace per render (per slot; asked of the library: salve_bev_workspace_bytes) and the verifier's activation ping-pong
+        buffers per sample (salve_resnet_workspace_bytes)."""
+        import ctypes
+
+        S = len(self.surfaces)
+        Hb, Wb = self.ras.bev_hw
+        lib = self.ras.lib
+        ws_render = lib.salve_bev_workspace_bytes(ctypes.byref(self.ras.cfg), 2) - lib.salve_bev_workspace_bytes(ctypes.byref(self.ras.cfg), 1)
+        act = lib.salve_resnet_workspace_bytes(self.engine.handle, 2) - lib.salve_resnet_workspace_bytes(self.engine.handle, 1)
+        tile = self.ras.crop * self.ras.crop * self.engine.in_channels * 2
+        bev = (S + (1 if self.has_layout else 0)) * Hb * Wb * 4
+        return int(nbuf * (bev + tile) + ws_slots * S * ws_render + act)
 
     # ------------------------------------------------------------------ panoramas
     def load_panos(self, rgb: np.ndarray, depth: np.ndarray) -> None:

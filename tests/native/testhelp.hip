@@ -39,7 +39,26 @@ __global__ __launch_bounds__(256) void burn_kernel(int iters, int mode, float* s
     }
     if (acc[0] + v == 12345.678f) sink[0] = acc[0];
 }
+
+// float4 device copy: the HBM copy microbenchmark of bench.py ("confirm the HBM peak with a copy microbenchmark on the
+// box").  Grid-stride over 16-byte lanes, four independent loads in flight per thread before the stores.
+__global__ __launch_bounds__(256) void copy16_kernel(float4* __restrict__ dst, const float4* __restrict__ src, long long n16) {
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
 }  // namespace
+
+extern "C" int salve_debug_copy16(void* dst, const void* src, long long n16, int32_t blocks, void* stream) {
+    if (!dst || !src || n16 <= 0 || blocks <= 0) return -1;
+    hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(dst),
+                       reinterpret_cast<const float4*>(src), n16);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 extern "C" int salve_debug_burn(int32_t blocks, int32_t iters, int32_t mode, float* sink, void* stream) {
     hipLaunchKernelGGL(burn_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, mode, sink);

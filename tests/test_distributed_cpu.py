@@ -32,10 +32,11 @@ def _worker(rank, world, port, n, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world", [(64, 2), (65, 2), (64, 3)])
+@pytest.mark.parametrize("n,world", [(64, 2), (65, 2), (64, 3), (32768, 8), (32771, 8)])
 def test_shard_and_all_gather(tmp_path, n, world):
     """Equal and unequal shards (65 rows over 2 ranks, 64 over 3): the single all_gather_into_tensor runs on blocks padded to
-    ceil(n / world) rows and the padding is dropped, so every rank ends with the table in its original order."""
+    ceil(n / world) rows and the padding is dropped, so every rank ends with the table in its original order.  (32768, 8) is BASELINE
+    config 4's table on its eight ranks; (32771, 8) the same with a row count eight does not divide.)"""
     mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
     table = synthetic.make_hypotheses(n, 5, seed=0)
     expect = torch.from_numpy(np.stack([table.theta_deg, table.t[:, 0].astype(np.float64)], 1)).float()
@@ -109,6 +110,7 @@ def test_bench_starts_its_own_launcher_for_several_gpus(monkeypatch):
         return subprocess.CompletedProcess(cmd, 7)
 
     monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)   # an 8-GPU node (the guard below is tested on its own)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
     with pytest.raises(SystemExit) as e:
@@ -119,6 +121,21 @@ def test_bench_starts_its_own_launcher_for_several_gpus(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
     assert cmd[-7].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert not torch.cuda.is_initialized()
+
+
+def test_bench_refuses_more_gpus_than_the_node_has(tmp_path):
+    """`python bench.py --gpus 8` on a node with fewer than 8 devices: non-zero exit with ONE clear line, before a launcher is started and
+    before any process initialises a GPU (this container shows none; a one-GPU box takes the same path for --gpus 8)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    proc = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert proc.returncode != 0
+    lines = [l for l in (proc.stdout + proc.stderr).splitlines() if l.strip()]
+    assert len(lines) == 1 and "--gpus 8" in lines[0] and "GPU(s)" in lines[0], lines
+    assert "torch.distributed" not in proc.stderr and "Traceback" not in proc.stderr
 
 
 def test_shards_partition_the_table():

@@ -32,7 +32,7 @@ def test_bench_under_the_launcher_with_rccl_on_one_gpu():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--hyps", "256",
-           "--panos", "8", "--force-dist", "--no-cpu-baseline"]
+           "--panos", "8", "--force-dist", "--no-cpu-baseline", "--no-calibration", "--no-config5"]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]

@@ -100,6 +100,7 @@ def tile_like_inputs(n, batch, seed=0):
     (50, ["floor_rgb_texture"], 5),
     (152, ["ceiling_rgb_texture", "floor_rgb_texture"], 2),
     (18, ["layout"], 3),
+    (34, ["floor_rgb_texture"], 3),                                    # the factory's fourth architecture (resnet_factory.py:39-40): basic blocks [3, 4, 6, 3]
     (50, ["ceiling_rgb_texture", "floor_rgb_texture", "layout"], 3),   # six images, 18 channels through the stem (early_fusion.py:30-32, 59-60)
 ])
 def test_logits_match_oracle(num_layers, modalities, batch):

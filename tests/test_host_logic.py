@@ -394,3 +394,26 @@ def test_fused_layout_host_side():
     assert fl.identity[2][0].shape == (0, 2) and fl.identity[2][1] == []
     with pytest.raises(_lib.SalveHipError):
         layout.pack_layouts(fl.posed, "cpu")
+
+
+def test_pick_launch_prefers_the_whole_shard_and_cuts_into_equal_whole_rounds():
+    """pipeline.pick_launch (pure host arithmetic): the whole shard in one launch when it fits the budget; otherwise the FEWEST equal
+    launches, in whole rounds of the 512 resident densify workgroups, never beyond the budget."""
+    from salve_amd.pipeline import pick_launch
+
+    MB = 1 << 20
+    assert pick_launch(4096, 14 * MB, 140 * 1024 * MB) == 4096                    # config 3: 57 GB of 140
+    assert pick_launch(4096, 20 * MB, 140 * 1024 * MB, surfaces=2) == 4096        # config 5: 80 GB of 140
+    assert pick_launch(32768, 14 * MB, 140 * 1024 * MB) == 8192                   # fit 10240 -> four equal launches of 8192 rows = 16 rounds each
+    n = pick_launch(5000, 14 * MB, 60 * 1024 * MB)                                # fit 4388 -> two launches of 2500 -> 2560 (5 rounds)
+    assert n == 2560 and n % 512 == 0
+    n = pick_launch(5000, 20 * MB, 60 * 1024 * MB, surfaces=2)                    # fit 3072 -> two launches of 2500 -> 2560 hypotheses = 5120 renders
+    assert n == 2560 and (2 * n) % 512 == 0
+    assert pick_launch(3, 14 * MB, 20 * MB) == 1                                  # one fits: one at a time
+    assert pick_launch(700, 14 * MB, 600 * 14 * MB) == 512                        # rounding UP (to 512) would leave the budget (600): stays inside
+    with pytest.raises(RuntimeError):
+        pick_launch(8, 14 * MB, MB)
+    with pytest.raises(ValueError):
+        pick_launch(0, 14 * MB, 1 << 40)
+    # a shard with more than 1024 renders is not cut into launches of 1024 or fewer while memory allows more
+    assert pick_launch(4096, 14 * MB, 3000 * 14 * MB) * 1 > 1024
