@@ -34,10 +34,13 @@ typedef enum {
     SALVE_ERR_WORKSPACE = -4
 } salve_status_t;
 
-#define SALVE_HIP_ABI_VERSION 5  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter;
+#define SALVE_HIP_ABI_VERSION 6  /* 3: device status word (densify, resnet_forward), in-window counts from salve_bev_scatter;
                                      4: salve_bev_tile_pairs; 5: panorama index (salve_bev_pano_index_*), the scatter stage writes the
                                      sparse image into out_bev (no key image in memory, salve_bev_workspace_init is gone), salve_resnet_create
-                                     takes its kernel selection as `flags` -- the library reads no environment variable */
+                                     takes its kernel selection as `flags` -- the library reads no environment variable;
+                                     6: SALVE_RESNET_CHAIN_STORE_ALL / SALVE_RESNET_NO_TRANSPOSED_TILES, out_flags bit 4 (renders densified in the
+                                     given order), a launch of >= 1025 renders keeps its dispatch order in the workspace's key image; unknown
+                                     `flags` / `out_flags` bits are refused with SALVE_ERR_BAD_ARG (ABI 5 ignored them) */
 
 /* Device status word: an optional device int32 the caller zeroes once and passes to the launches below.  Kernels OR bits
  * into it when something went wrong that an int return value cannot report (the launch is asynchronous); the caller
@@ -73,7 +76,11 @@ typedef struct {
     int32_t mask_k;             /* box-filter size of remove_hallucinated_content; 11 */
     float depth_scale;          /* uint16 depth -> metres, applied in float32 (:367); 0.001f */
     int32_t out_flags;          /* 0 for render_bev_image; 1: no vertical flip, 2: no mask (plain interpolation), 4: the renders of a
-                                   launch are densified in the order given (default: the costly ones first -- same images, shorter tail) */
+                                   launch are densified in the order given (default: the costly ones first -- same images, shorter tail).
+                                   Any other bit: SALVE_ERR_BAD_ARG.  The scatter and the densify call of the same renders must be given the
+                                   SAME out_flags and n: from 1025 renders per launch the scatter stage leaves a cost per render, and the
+                                   densify stage its dispatch order, in the workspace's key image (which the single-render utility paths
+                                   salve_bev_scatter_points / salve_bev_keys_from_pixels overwrite) */
     double win_xmin, win_xmax, win_ymin, win_ymax; /* prune_to_2d_bbox window, inclusive (:38-45); -5, 5, -5, 5 */
     double img_tx, img_ty, img_scale; /* bevimg_Sim2_world: (p + t) * s (bevparams.py:69-78); 5, 5, 50 */
     double rot_pre[4];          /* rotmat2d(-90), row-major float64 exactly as numpy computes it (:443) */
@@ -295,6 +302,9 @@ typedef struct {
 #define SALVE_RESNET_CHAIN_NO_SPLIT 512  /* its 8-wave form for the 256-channel shapes too */
 #define SALVE_RESNET_CHAIN_STORE_ALL 1024 /* every pixel of a stage's last block output is stored (default: only the even rows and columns
                                              that its one reader, the next stage's stride-2 projection shortcut, samples) */
+#define SALVE_RESNET_NO_TRANSPOSED_TILES 2048 /* the fused 56 x 56 blocks with a fourth, half-empty tile column of 8 x 16 tiles instead of
+                                             the transposed 16 x 8 tiles that cover the last 8 image columns exactly */
+#define SALVE_RESNET_ALL_FLAGS 4095      /* salve_resnet_create refuses any other bit */
 
 /* Creates a handle that owns device copies of the (host) weight blobs.  NULL on failure.  flags: SALVE_RESNET_* (0). */
 void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,

@@ -17,7 +17,7 @@ import os
 LIB_PATH = Path(os.environ.get("SALVE_HIP_LIB") or (Path(__file__).resolve().parent / "libsalve_hip.so"))
 
 SALVE_OK = 0
-EXPECTED_ABI = 5          # include/salve_hip.h: SALVE_HIP_ABI_VERSION
+EXPECTED_ABI = 6          # include/salve_hip.h: SALVE_HIP_ABI_VERSION
 TILE_F32_NCHW = 0
 TILE_F16_NHWC = 1
 TILE_U8X4 = 2
@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = (
 # salve_resnet_create flags (include/salve_hip.h: SALVE_RESNET_*): kernel selection for the bit-identity tests; 0 = product
 RESNET_CONV_IGEMM_ONLY, RESNET_CONV8_WHEREVER, RESNET_ROUND_ROBIN_TILES, RESNET_NO_STEM_FUSE, RESNET_NO_BLOCK_FUSE = 1, 2, 4, 8, 16
 RESNET_NO_PROJ_FUSE, RESNET_NO_CHAIN, RESNET_CHAIN_EXPAND_ONLY, RESNET_CHAIN_16_WAVES, RESNET_CHAIN_NO_SPLIT = 32, 64, 128, 256, 512
-RESNET_CHAIN_STORE_ALL = 1024
+RESNET_CHAIN_STORE_ALL, RESNET_NO_TRANSPOSED_TILES = 1024, 2048
 STATUS_WALK_FAILED = 1
 STATUS_FP16_RANGE = 2
 STATUS_BAD_HYPOTHESIS = 4

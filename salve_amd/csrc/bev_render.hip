@@ -321,6 +321,11 @@ static int ensure_star_table() {
 // cluttered / noisy scenes, and of five such counts this one was good on all three scenes).
 // bev_order_kernel: ONE workgroup, counting sort by cost[] (summed by the splat's tiles with one atomic each), descending, into
 // order[] (ties in any order: the atomics of the scatter decide, nothing observable depends on it).
+// uint32 words of one render's two bitmaps ([occupancy | non-empty][tile][TILE_H rows][TILE_WORDS]) in the workspace: the ONE definition of that
+// layout, used by carve_workspace (host) and by bev_densify_kernel to find order[] behind the bitmaps of its launch.
+__host__ __device__ inline size_t bitmap_words_hw(int H, int W) {
+    return (size_t)2 * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H) * TILE_H * TILE_WORDS;
+}
 constexpr int DENSIFY_ORDERED = 256;      // DensifyCfg::out_flags, set by bev_stage only: order[] is valid
 constexpr int ORDER_BINS = 1024;
 constexpr int ORDER_MIN_RENDERS = 1025;   // more than two rounds of the 512 resident workgroups.  Measured (tools/densify_order_threshold.py, costly
@@ -380,8 +385,14 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     //  eight spill reloads into the lean-walk loop, tools/densify_spills.py)
     int rid = blockIdx.x;
     if (c.out_flags & DENSIFY_ORDERED) {
-        const size_t words_per_render = (size_t)2 * ((c.W + TILE_W - 1) / TILE_W) * ((c.H + TILE_H - 1) / TILE_H) * TILE_H * TILE_WORDS;
-        rid = reinterpret_cast<const int32_t*>(bitmaps_all + (size_t)gridDim.x * words_per_render)[gridDim.x + blockIdx.x];
+        // order[] = the second int32 array of the workspace's key image, which carve_workspace puts behind the bitmaps of the launch's n = gridDim.x
+        // renders (ONE layout function for host and kernel: bitmap_words_hw).  A value outside the launch -- a stale or foreign workspace -- must not
+        // become an address: the workgroup leaves and the launch reports the failure.
+        rid = reinterpret_cast<const int32_t*>(bitmaps_all + (size_t)gridDim.x * bitmap_words_hw(c.H, c.W))[gridDim.x + blockIdx.x];
+        if ((unsigned)rid >= gridDim.x) {
+            if (threadIdx.x == 0 && status) atomicOr(status, SALVE_STATUS_WALK_FAILED);
+            return;
+        }
     }
     const int flip = (c.out_flags & 1) ? -1 : H - 1;
     uint32_t* bev = bev_all + (size_t)rid * H * W;
@@ -961,6 +972,7 @@ bool make_devcfg(const salve_bev_config_t* cfg, DevCfg* d) {
     if (cfg->bev_h < 2 || cfg->bev_w < 2 || cfg->bev_h >= SD_MAX_DIM || cfg->bev_w >= SD_MAX_DIM) return salve_fail("bev size out of range");
     if (cfg->mask_k < 1 || (cfg->mask_k & 1) == 0 || cfg->mask_k / 2 > MASK_MAX_HALF) return salve_fail("mask_k must be odd and <= 17");
     if (cfg->n_slices < 1 || cfg->n_slices > 62) return salve_fail("n_slices out of range");
+    if (cfg->out_flags & ~7) return salve_fail("unknown bit in out_flags (1: no flip, 2: no mask, 4: given order): a caller written for another ABI version");
     d->pano_h = cfg->pano_h; d->pano_w = cfg->pano_w; d->crop_rows = cfg->crop_rows;
     d->rows = cfg->pano_h - 2 * cfg->crop_rows;
     d->npts = d->rows * cfg->pano_w;
@@ -1011,10 +1023,7 @@ struct Workspace {
     uint32_t* keys;   // one image
 };
 
-static size_t bitmap_words(const DevCfg& d) {
-    const size_t ntiles = (size_t)((d.W + TILE_W - 1) / TILE_W) * ((d.H + TILE_H - 1) / TILE_H);
-    return 2 * ntiles * TILE_H * TILE_WORDS;
-}
+static size_t bitmap_words(const DevCfg& d) { return bitmap_words_hw(d.H, d.W); }
 
 static size_t workspace_per_render(const DevCfg& d) {
     const size_t npx = (size_t)d.H * d.W;

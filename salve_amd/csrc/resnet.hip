@@ -452,6 +452,14 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const uint16_t* __restr
 //   GEMM 3  Y[pixel][4 MID] = relu(t2 . Wc^T + bc + X[pixel]), 128 output channels at a time, epilogue through LDS with
 //           16-byte coalesced residual loads and stores as in conv_igemm_kernel.
 // MFMA operands are swapped (acc = W-fragment x A-fragment) so that a lane owns 4 consecutive channels of one pixel.
+//
+// TRANSPOSED TILES (r6).  A 56-pixel image row is 3.5 tiles of 16 columns: with four tile columns the fourth is half empty -- 28 tiles
+// per image for 24.5 tiles' worth of pixels, an eighth of the block's three GEMMs multiplying rows that do not exist.  The strip of TH
+// columns right of the last whole tile column is therefore covered by tiles of 16 rows x TH columns -- the SAME tile with the roles of
+// row and column exchanged (tile pixel (r, c) is image pixel (oy0 + c, ox0 + r)); its halo is the same (TH + 2) x 18 pixels, every LDS
+// offset, fragment read and counted wait stays where it is, and only the image addresses (GEMM 1's rows, the output stores) and the
+// tap -> halo offset of GEMM 2 exchange their coordinates.  GEMM 2 still walks the taps in the IMAGE's (dy, dx) order, so the sums are
+// the same sums in the same order: bit-identical to the three-kernel path.  56 x 56: 21 + 4 = 25 tiles per image instead of 28.
 struct BottleneckArgs {
     const uint16_t* x;
     uint16_t* y;
@@ -459,6 +467,7 @@ struct BottleneckArgs {
     const float *ba, *bb, *bc;
     const uint16_t* zeros;
     int B, H, W, tiles_x, tiles_y;
+    int tiles_t;      // transposed tiles per image (below): 0, or ceil(H / 16) tiles of 16 rows x TH columns for the strip right of tiles_x * 16
     int32_t* status;
     int xcd_contig;   // 1: every XCD owns a contiguous range of tiles (xcd_linear), so the tiles of one image share an L2
 };
@@ -510,11 +519,15 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases need no per-load readfirstlane
     const int wr = wave >> 1, wc = wave & 1;   // GEMM 2 / 3
     const int wm = wave & 3, wn = wave >> 2;   // GEMM 1
-    int t = xcd_linear(blockIdx.x, gridDim.x, p.xcd_contig);
-    const int tx = t % p.tiles_x; t /= p.tiles_x;
-    const int ty = t % p.tiles_y;
-    const int b = t / p.tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int t = xcd_linear(blockIdx.x, gridDim.x, p.xcd_contig);
+    const int n_upright = p.tiles_x * p.tiles_y, per_image = n_upright + p.tiles_t;
+    const int b = t / per_image, kt_img = t % per_image;
+    const bool TR = kt_img >= n_upright;   // a transposed tile: 16 image rows x TH image columns (workgroup-uniform)
+    const int oy0 = TR ? (kt_img - n_upright) * 16 : (kt_img / p.tiles_x) * TH;
+    const int ox0 = TR ? p.tiles_x * 16 : (kt_img % p.tiles_x) * 16;
+    // tile pixel (r, c) -> image pixel
+    auto img_y = [&](int r, int c) { return oy0 + (TR ? c : r); };
+    auto img_x = [&](int r, int c) { return ox0 + (TR ? r : c); };
     const uint16_t* ximg = p.x + (long long)b * p.H * p.W * CIN;
     const int frag_row = lane & 15, frag_q = lane >> 4;
     const int row_base = tid >> 3;
@@ -556,7 +569,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
 #pragma unroll
         for (int i = 0; i < M1 / 64; i++) {
             const int h = row_base + 64 * i;
-            const int hy = oy0 - 1 + h / HC, hx = ox0 - 1 + h % HC;
+            const int hy = img_y(h / HC - 1, h % HC - 1), hx = img_x(h / HC - 1, h % HC - 1);
             const bool ok = h < HALO && hy >= 0 && hy < p.H && hx >= 0 && hx < p.W;
             rowp[i] = ok ? ximg + ((long long)hy * p.W + hx) * CIN + chunk * 8 : nullptr;
         }
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
 #pragma unroll
         for (int i = 0; i < MT1; i++) {
             const int h = (wm * MT1 + i) * 16 + frag_row;
-            const int hy = oy0 - 1 + h / HC, hx = ox0 - 1 + h % HC;
+            const int hy = img_y(h / HC - 1, h % HC - 1), hx = img_x(h / HC - 1, h % HC - 1);
             const bool inside = h < HALO && hy >= 0 && hy < p.H && hx >= 0 && hx < p.W;
             const uint32_t keep = inside ? 0xFFFFFFFFu : 0u;   // (a mask, not a select around the conversions: hipcc made branches of those)
             const int swz = MID == 64 ? ((h >> 1) & 7) : (h & 15);
@@ -667,12 +680,13 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                 const int ktile = st * STAGE_TILES + q;
                 const int tap = ktile / KT_MID, kh = ktile % KT_MID;  // kh: which 64 channels of t1
                 const int dy = tap / 3, dx = tap % 3;
+                const int ro = TR ? dx : dy, co = TR ? dy : dx;   // the tap's offset in TILE rows / columns (transposed tiles: exchanged)
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
                     act8 af[RT], bfr[NT2];
 #pragma unroll
                     for (int i = 0; i < RT; i++) {
-                        const int h = (wr * RT + i + dy) * HC + dx + frag_row;
+                        const int h = (wr * RT + i + ro) * HC + co + frag_row;
                         const int swz = MID == 64 ? ((h >> 1) & 7) : (h & 15);
                         af[i] = *reinterpret_cast<const act8*>(T1 + h * MID + (((kh * 8 + ks * 4 + frag_q) ^ swz) << 3));
                     }
@@ -717,8 +731,8 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
 #pragma unroll
         for (int i = 0; i < MO / 64; i++) {         // X centre tile (L2: GEMM 1 has just read it), lands with the first weights
             const int r = row_base + 64 * i;
-            const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
-            const uint16_t* src = ox < p.W ? ximg + ((long long)oy * p.W + ox) * CIN + chunk * 8 : p.zeros;
+            const int oy = img_y(r >> 4, r & 15), ox = img_x(r >> 4, r & 15);
+            const uint16_t* src = (ox < p.W && oy < p.H) ? ximg + ((long long)oy * p.W + ox) * CIN + chunk * 8 : p.zeros;
             __builtin_amdgcn_global_load_lds((global_cptr)src, (lds_ptr)(Xc + (wave * 8 + 64 * i) * 64), 16, 0, 0);
         }
         for (int nc = 0; nc < C4 / 64; nc++) {
@@ -771,8 +785,8 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             for (int it = 0; it < C_ITERS; it++) {
                 const int id = tid + it * BN_THREADS;
                 const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
-                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (ox < p.W)
+                const int oy = img_y(m >> 4, m & 15), ox = img_x(m >> 4, m & 15);
+                if (ox < p.W && oy < p.H)
                     store16_stream(yimg + ((long long)oy * p.W + ox) * C4 + nc * 64 + ch * 8, *reinterpret_cast<const uint4*>(Cp + m * LDC_P + ch * 8));
             }
             __syncthreads();  // staging and weight chunk are reused by the next chunk
@@ -837,8 +851,8 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             for (int it = 0; it < C_ITERS; it++) {
                 const int id = tid + it * BN_THREADS;
                 const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
-                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (ox < p.W)
+                const int oy = img_y(m >> 4, m & 15), ox = img_x(m >> 4, m & 15);
+                if (ox < p.W && oy < p.H)
                     store16_stream(yimg + ((long long)oy * p.W + ox) * C4 + nc * 128 + ch * 8, *reinterpret_cast<const uint4*>(Cs + m * LDC + ch * 8));
             }
             __syncthreads();  // staging and Wc tile are reused by the next chunk
@@ -867,6 +881,7 @@ struct ResnetHandle {
     int chain_split = 1;                  // SALVE_RESNET_CHAIN_NO_SPLIT: the 8-wave form for the 256-channel shapes too
     int chain_dbg = 0, chain_waves = 8;   // chain_dbg: ablation build only (timing-only switches of expand_chain_kernel); SALVE_RESNET_CHAIN_16_WAVES
     std::vector<int> y_even;              // per op: 1 = the chained expand convolution stores only Y's even pixels (expand_chain.h: y_even_w)
+    int no_transposed_tiles = 0;          // SALVE_RESNET_NO_TRANSPOSED_TILES: the fused blocks' fourth, half-empty tile column instead (bit-identity tests, A/B)
 };
 
 // expand_chain_kernel shapes: (MID, MIDN) of the chained form, MID of the expand-only form
@@ -933,6 +948,10 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
         salve_fail("salve_resnet_create: null argument");
         return nullptr;
     }
+    if (flags & ~SALVE_RESNET_ALL_FLAGS) {
+        salve_fail("salve_resnet_create: unknown bit in flags (SALVE_RESNET_*): a caller written for another ABI version");
+        return nullptr;
+    }
     ResnetHandle* h = new ResnetHandle();
     h->num_layers = num_layers;
     h->in_channels = in_channels;
@@ -959,6 +978,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
         for (size_t i = 0; i < h->ops.size(); i++) h->wide[i] = choose_wide(h->ops[i], mode);
     }
     h->xcd_contig = (flags & SALVE_RESNET_ROUND_ROBIN_TILES) ? 0 : 1;
+    h->no_transposed_tiles = (flags & SALVE_RESNET_NO_TRANSPOSED_TILES) ? 1 : 0;
     h->stem.assign(h->ops.size(), 0);
     {
         const bool enable = !(flags & SALVE_RESNET_NO_STEM_FUSE);   // else: the implicit-GEMM stem and the separate max-pool
@@ -1140,10 +1160,14 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.ba = h->d_params + o.b_off; a.bb = h->d_params + ob.b_off; a.bc = h->d_params + oc.b_off;
             a.zeros = h->d_zeros;
             a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status; a.xcd_contig = h->xcd_contig;
-            a.tiles_x = (o.Wi + 15) / 16;
             const bool narrow = o.Cout == 64;  // 64 mid channels: 8 x 16 pixel tiles; 128: 4 x 16
-            a.tiles_y = o.Hi / (narrow ? 8 : 4);
-            const long long grid = (long long)batch * a.tiles_x * a.tiles_y;
+            const int th = narrow ? 8 : 4;
+            // a strip of exactly TH columns right of the whole tile columns (56 = 3 x 16 + 8) is covered by transposed tiles of 16 rows
+            const bool strip = (o.Wi % 16) == th && !h->no_transposed_tiles;
+            a.tiles_x = strip ? o.Wi / 16 : (o.Wi + 15) / 16;
+            a.tiles_y = o.Hi / th;
+            a.tiles_t = strip ? (o.Hi + 15) / 16 : 0;
+            const long long grid = (long long)batch * (a.tiles_x * a.tiles_y + a.tiles_t);
             if (grid > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
             if (h->fused[oi] == 2) hipLaunchKernelGGL((bottleneck_kernel<64, 8, true>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
             else if (narrow) hipLaunchKernelGGL((bottleneck_kernel<64, 8>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);

@@ -450,8 +450,15 @@ SD_FN void sd_share_best(const SdGrid& g, const SdEdge& e, SdBest* best, int* sh
             if (sd_beats(e, w, ox, oy, ol)) { w.px = ox; w.py = oy; w.lam = ol; }
         }
         // (`changed` is never empty here, and the minimum's own lane is a contender in exact arithmetic; should the float thinning
-        //  ever drop every lane -- a NaN lambda would --, the candidate shared so far stays instead of an apex of (-1, -1))
-        if (w.px < 0) return;
+        //  ever drop every lane -- a NaN lambda would --, EVERY lane goes back to the candidate shared so far, so that the function's
+        //  post-condition -- all lanes hold the same best apex -- survives: a lane that kept its private candidate would cut its rows
+        //  with a circle of its own in the next sweep)
+        if (w.px < 0) {
+            float lam;
+            if (*shared_x >= 0 && sd_lambda(e, *shared_x, *shared_y, &lam)) sd_best_set(*best, e, *shared_x, *shared_y, lam);
+            else { best->px = -1; best->py = -1; }
+            return;
+        }
         sd_best_set(*best, e, w.px, w.py, w.lam);
         *shared_x = w.px;
         *shared_y = w.py;

@@ -286,12 +286,94 @@ def test_fused_bottleneck_is_bit_identical_to_three_kernels():
     x = torch.randn(3, 224, 224, 8).to(torch.float16).to(DEV)
     x[..., 6:] = 0
     outs = []
-    for flags in (0, _lib.RESNET_NO_BLOCK_FUSE, _lib.RESNET_NO_PROJ_FUSE):
+    for flags in (0, _lib.RESNET_NO_BLOCK_FUSE, _lib.RESNET_NO_PROJ_FUSE, _lib.RESNET_NO_TRANSPOSED_TILES):
         eng = hip_resnet.HipResNet(model.state_dict(), 50, torch.device(DEV), flags=flags)
         outs.append(eng.forward_nhwc(x).clone())
         torch.cuda.synchronize()
     assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+
+
+def _run_program(bld, x_nhwc, flags, read_bufs):
+    """A builder's op program through salve_resnet_create(flags) / salve_resnet_forward; returns the named workspace buffers (int16 bits)."""
+    lib = _lib.load()
+    ops = np.array(bld.ops, dtype=hip_resnet.OP_DTYPE)
+    wb, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
+    B, Cp = int(x_nhwc.shape[0]), int(x_nhwc.shape[3])
+    h = lib.salve_resnet_create(0, Cp, ops.ctypes.data_as(ctypes.c_void_p), len(ops), wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
+                                pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, int(flags))
+    assert h, lib.salve_last_error()
+    h = ctypes.c_void_p(h)
+    need = lib.salve_resnet_workspace_bytes(h, B)
+    n_bufs = int(max(o["out_buf"] for o in ops)) + 1
+    ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
+    base_off = (-ws.data_ptr()) % 256
+    view = ws[base_off:base_off + (need - 256)].view(torch.int16)
+    view.fill_(0x7E00)                       # fp16 NaN: a pixel a kernel fails to write shows up
+    per_buf = view.numel() // n_bufs
+    logits = torch.zeros((B, 2), dtype=torch.float32, device=DEV)
+    xd = x_nhwc.to(DEV).contiguous()
+    word = torch.zeros(1, dtype=torch.int32, device=DEV)
+    st = lib.salve_resnet_forward(h, ctypes.c_void_p(xd.data_ptr()), B, ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                  ws.numel(), ctypes.c_void_p(word.data_ptr()), None)
+    torch.cuda.synchronize()
+    assert st == 0, lib.salve_last_error()
+    assert int(word.item()) == 0
+    out = {}
+    for i, (Ho, Wo, C) in read_bufs.items():
+        out[i] = view[i * per_buf: i * per_buf + B * Ho * Wo * C].clone().cpu().reshape(B, Ho, Wo, C)
+    lib.salve_resnet_destroy(h)
+    return out
+
+
+@pytest.mark.parametrize("H,W,B", [(56, 56, 3), (24, 40, 2), (16, 24, 5), (32, 48, 2)])
+def test_fused_block_outputs_are_bit_identical_tensor_for_tensor(H, W, B):
+    """The two fused 56 x 56 block forms (projection block, plain block) against the three-kernel path, the whole OUTPUT TENSOR of each
+    block, for the default tiling -- the strip of 8 columns right of the whole 16-column tiles covered by TRANSPOSED tiles of 16 rows x 8
+    columns (56 = 3 x 16 + 8; 40 = 2 x 16 + 8 with a half-empty last transposed tile at H = 24; 24 = 16 + 8) -- and for the tiling with a
+    half-empty last tile column (SALVE_RESNET_NO_TRANSPOSED_TILES); W = 48 has no strip.  GEMM 2 of a transposed tile walks the taps in
+    the image's (dy, dx) order, so every pixel is the same sum in the same order: bits must agree, and no output pixel may stay unwritten
+    (the activation buffers start as fp16 NaNs)."""
+    g = torch.Generator().manual_seed(H * 100 + W)
+    rnd = lambda *shape, s=1.0: torch.randn(*shape, generator=g) * s
+    bld = hip_resnet._Builder()
+    NI, NB = hip_resnet.NET_INPUT, hip_resnet.NO_BUF
+    # buffer 0 = relu(1x1 64 -> 64 of the input): the blocks need their input in a workspace buffer
+    bld.conv(rnd(64, 64, 1, 1, s=0.15), rnd(64, s=0.1), NI, 0, NB, H, W, 1, 0, True)
+    # projection block (first block of layer 1): 64 -> 64 -> 64 -> 256, shortcut 1x1 64 -> 256 folded into the last convolution
+    bld.conv(rnd(64, 64, 1, 1, s=0.15), rnd(64, s=0.1), 0, 1, NB, H, W, 1, 0, True)
+    bld.conv(rnd(64, 64, 3, 3, s=0.06), rnd(64, s=0.1), 1, 2, NB, H, W, 1, 1, True)
+    bld.conv1x1_with_shortcut(rnd(256, 64, 1, 1, s=0.12), rnd(256, s=0.1), 2, 3, H, W, rnd(256, 64, 1, 1, s=0.12), rnd(256, s=0.1), 0, H, W, 1)
+    # plain block: 256 -> 64 -> 64 -> 256 + residual
+    bld.conv(rnd(64, 256, 1, 1, s=0.08), rnd(64, s=0.1), 3, 1, NB, H, W, 1, 0, True)
+    bld.conv(rnd(64, 64, 3, 3, s=0.06), rnd(64, s=0.1), 1, 2, NB, H, W, 1, 1, True)
+    bld.conv(rnd(256, 64, 1, 1, s=0.12), rnd(256, s=0.1), 2, 4, 3, H, W, 1, 0, True)
+    x = rnd(B, H, W, 64).to(torch.float16)
+    read = {3: (H, W, 256), 4: (H, W, 256)}
+    ref = _run_program(bld, x, _lib.RESNET_NO_BLOCK_FUSE, read)
+    assert not (ref[3] == 0x7E00).any() and not (ref[4] == 0x7E00).any()
+    assert (ref[4] != 0).float().mean() > 0.2, "the test block should not be dead"
+    for flags in (0, _lib.RESNET_NO_TRANSPOSED_TILES, _lib.RESNET_ROUND_ROBIN_TILES):
+        got = _run_program(bld, x, flags, read)
+        for i in (3, 4):
+            bad = (got[i] != ref[i]).any(-1)
+            assert not bad.any(), f"flags {flags}, buffer {i}: {int(bad.sum())} pixels differ, first at {bad.nonzero()[0].tolist()}"
+
+
+def test_unknown_flag_bits_are_refused():
+    """ABI 6: salve_resnet_create refuses flag bits it does not know (a caller written for another ABI version), so that a bit-identity
+    test can never compare a kernel selection with itself; the rasteriser's out_flags likewise."""
+    lib = _lib.load()
+    bld = hip_resnet._Builder()
+    bld.conv(torch.zeros(64, 64, 1, 1), torch.zeros(64), hip_resnet.NET_INPUT, 0, hip_resnet.NO_BUF, 8, 8, 1, 0, True)
+    ops = np.array(bld.ops, dtype=hip_resnet.OP_DTYPE)
+    wb, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
+    mk = lambda flags: lib.salve_resnet_create(0, 64, ops.ctypes.data_as(ctypes.c_void_p), 1, wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
+                                               pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, flags)
+    assert not mk(4096) and b"unknown bit" in lib.salve_last_error()
+    h = mk(_lib.RESNET_NO_TRANSPOSED_TILES | _lib.RESNET_CHAIN_STORE_ALL)
+    assert h
+    lib.salve_resnet_destroy(ctypes.c_void_p(h))
 
 
 @pytest.mark.parametrize("layers,batch", [(50, 3), (50, 37), (152, 2)])
