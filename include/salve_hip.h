@@ -38,7 +38,7 @@ typedef enum {
                                      4: salve_bev_tile_pairs; 5: panorama index (salve_bev_pano_index_*), the scatter stage writes the
                                      sparse image into out_bev (no key image in memory, salve_bev_workspace_init is gone), salve_resnet_create
                                      takes its kernel selection as `flags` -- the library reads no environment variable;
-                                     6: SALVE_RESNET_CHAIN_STORE_ALL / SALVE_RESNET_NO_TRANSPOSED_TILES, out_flags bit 4 (renders densified in the
+                                     6: SALVE_RESNET_CHAIN_STORE_ALL / _NO_TRANSPOSED_TILES / _NO_NEXT_FUSE, out_flags bit 4 (renders densified in the
                                      given order), a launch of >= 1025 renders keeps its dispatch order in the workspace's key image; unknown
                                      `flags` / `out_flags` bits are refused with SALVE_ERR_BAD_ARG (ABI 5 ignored them) */
 
@@ -304,7 +304,9 @@ typedef struct {
                                              that its one reader, the next stage's stride-2 projection shortcut, samples) */
 #define SALVE_RESNET_NO_TRANSPOSED_TILES 2048 /* the fused 56 x 56 blocks with a fourth, half-empty tile column of 8 x 16 tiles instead of
                                              the transposed 16 x 8 tiles that cover the last 8 image columns exactly */
-#define SALVE_RESNET_ALL_FLAGS 4095      /* salve_resnet_create refuses any other bit */
+#define SALVE_RESNET_NO_NEXT_FUSE 4096   /* the last fused block of layer 1 without the next block's first 1x1 convolution as its fourth GEMM
+                                             (with it, that block stores only the even pixels of its own output unless ..._CHAIN_STORE_ALL) */
+#define SALVE_RESNET_ALL_FLAGS 8191      /* salve_resnet_create refuses any other bit */
 
 /* Creates a handle that owns device copies of the (host) weight blobs.  NULL on failure.  flags: SALVE_RESNET_* (0). */
 void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_resnet_op_t* ops, int32_t n_ops,

@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = (
 # salve_resnet_create flags (include/salve_hip.h: SALVE_RESNET_*): kernel selection for the bit-identity tests; 0 = product
 RESNET_CONV_IGEMM_ONLY, RESNET_CONV8_WHEREVER, RESNET_ROUND_ROBIN_TILES, RESNET_NO_STEM_FUSE, RESNET_NO_BLOCK_FUSE = 1, 2, 4, 8, 16
 RESNET_NO_PROJ_FUSE, RESNET_NO_CHAIN, RESNET_CHAIN_EXPAND_ONLY, RESNET_CHAIN_16_WAVES, RESNET_CHAIN_NO_SPLIT = 32, 64, 128, 256, 512
-RESNET_CHAIN_STORE_ALL, RESNET_NO_TRANSPOSED_TILES = 1024, 2048
+RESNET_CHAIN_STORE_ALL, RESNET_NO_TRANSPOSED_TILES, RESNET_NO_NEXT_FUSE = 1024, 2048, 4096
 STATUS_WALK_FAILED = 1
 STATUS_FP16_RANGE = 2
 STATUS_BAD_HYPOTHESIS = 4

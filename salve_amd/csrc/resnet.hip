@@ -468,6 +468,11 @@ struct BottleneckArgs {
     const uint16_t* zeros;
     int B, H, W, tiles_x, tiles_y;
     int tiles_t;      // transposed tiles per image (below): 0, or ceil(H / 16) tiles of 16 rows x TH columns for the strip right of tiles_x * 16
+    // NEXT form (the last block of layer 1): the FOLLOWING block's first 1x1 convolution rides along as a fourth GEMM on the Y tile
+    const uint16_t* wd;   // [MIDN][4 MID] fp16, BatchNorm folded
+    const float* bd;
+    uint16_t* t1n;        // [B, H, W, MIDN]
+    int y_even;           // 1: only the pixels of Y with even row and column are stored (its one other reader samples it at stride 2)
     int32_t* status;
     int xcd_contig;   // 1: every XCD owns a contiguous range of tiles (xcd_linear), so the tiles of one image share an L2
 };
@@ -481,8 +486,16 @@ __device__ __forceinline__ void store16_stream(uint16_t* p, uint4 v) { *reinterp
 // PROJ: the first block of layer 1 -- its input has MID channels (not 4 MID) and its shortcut is a 1x1 projection, which rides
 //       in GEMM 3 as MID more k: Y = relu([t2 | X] . [Wc | Ws]^T + (bc + bs)), the weight rows K-concatenated as the
 //       three-kernel path stores them (conv1x1_with_shortcut), 64 output channels at a time.
-template <int MID, int TH, bool PROJ = false>
+// NEXT: the last block of a stage whose successor keeps the resolution in its first convolution (layer 1 -> layer 2: torchvision's v1.5
+//       puts the stride on the 3x3) -- that convolution,  t1' = relu(Wd . Y + bd)  with MIDN = 2 MID output channels, is a FOURTH GEMM on
+//       the Y tile while each 128-channel chunk of it sits in the staging tile (fp16, exactly the values the separate launch would read
+//       back): K = 4 MID in the same ascending k-tiles of 64, so t1' is bit-identical to conv_igemm_kernel's; its accumulators live
+//       across the two chunks, Wd streams through the Wc chunk's buffer (and, in the last chunk, through the dead t2).  Y itself is then
+//       read from memory only by the next stage's stride-2 projection shortcut: with y_even only a quarter of it is stored.  Per 4096
+//       samples that removes the launch that re-read Y (6.6 GB) to write t1' (3.3 GB), and 4.9 GB of Y's stores.
+template <int MID, int TH, bool PROJ = false, bool NEXT = false>
 __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArgs p) {
+    static_assert(!NEXT || (!PROJ && MID == 64 && TH == 8), "the NEXT form is written for the plain 64-channel block");
     constexpr int C4 = 4 * MID;
     constexpr int CIN = PROJ ? MID : C4;   // channels of the block's input
     constexpr int HC = 18, HALO = (TH + 2) * HC;
@@ -792,10 +805,34 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
             __syncthreads();  // staging and weight chunk are reused by the next chunk
         }
     } else
-    // ------------------------------------------------------------------ GEMM 3: Y = relu(t2 . Wc^T + bc + X)
+    // ------------------------------------------------------------------ GEMM 3: Y = relu(t2 . Wc^T + bc + X)   (+ NEXT: GEMM 4 on Y)
     {
         constexpr int CH_PER_ROW = 128 / 8;
         constexpr int C_ITERS = (MO * CH_PER_ROW) / BN_THREADS;
+        constexpr int MIDN = 2 * MID;                        // NEXT: output channels of the following block's first convolution (128)
+        f32x4 acc4[NEXT ? RT : 1][NEXT ? MIDN / 32 : 1];     // NEXT: t1' accumulators, 16 pixels x 16 channels each, alive across both chunks
+        // NEXT: Wd k-tile KT (MIDN rows x 64 k of the [MIDN][4 MID] matrix) -> DST, laid out like a Wc tile (128 rows x 128 bytes, source-side swizzle)
+#define ISSUE_WD(KT, DST)                                                                                              \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < MIDN / 64; j++)                                                          \
+            __builtin_amdgcn_global_load_lds((global_cptr)(p.wd + (long long)(row_base + 64 * j) * C4 + (KT) * 64 + chunk * 8), \
+                                             (lds_ptr)((DST) + (wave * 8 + 64 * j) * 64), 16, 0, 0);                   \
+    }
+        // NEXT: one k-tile of GEMM 4: A = 64 channels of the Y chunk in the staging tile (rows of LDC halves), B = a Wd tile
+#define GEMM4_KTILE(ACOL, BT)                                                                                          \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++) {                                                             \
+            act8 af[RT], bfr[MIDN / 32];                                                                               \
+            _Pragma("unroll") for (int i = 0; i < RT; i++)                                                             \
+                af[i] = *reinterpret_cast<const act8*>(Cs + ((wr * RT + i) * 16 + frag_row) * LDC + (ACOL) + ks * 32 + frag_q * 8); \
+            const int slot = ((ks * 4 + frag_q) ^ ((frag_row >> 1) & 7)) * 8;                                          \
+            _Pragma("unroll") for (int j = 0; j < MIDN / 32; j++)                                                      \
+                bfr[j] = *reinterpret_cast<const act8*>((BT) + ((wc * (MIDN / 32) + j) * 16 + frag_row) * 64 + slot);  \
+            _Pragma("unroll") for (int i = 0; i < RT; i++)                                                             \
+                _Pragma("unroll") for (int j = 0; j < MIDN / 32; j++)                                                  \
+                    acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc4[i][j], 0, 0, 0);          \
+        }                                                                                                              \
+    }
 #pragma unroll
         for (int nc = 0; nc < C4 / 128; nc++) {
             // Wc chunk: 128 output channels x MID, as KT_MID tiles of 128 rows x 64
@@ -807,56 +844,128 @@ __global__ __launch_bounds__(BN_THREADS, 4) void bottleneck_kernel(BottleneckArg
                                                      (lds_ptr)(BsC + q * 128 * 64 + (wave * 8 + 64 * j) * 64), 16, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();  // (first chunk: also orders the t2 stores)
-            f32x4 acc[RT][4];
+            // (NEXT: the chunk in two passes of 64 channels -- 16 accumulator registers next to the 32 of GEMM 4 and the residual's; in one
+            //  pass the kernel needs 50 registers more than the 128 that four waves per SIMD leave, and a scratch reload is a vmcnt load
+            //  queued behind the LDS-DMA stages)
+            constexpr int NH = NEXT ? 2 : 1, JN = 4 / NH;
 #pragma unroll
-            for (int i = 0; i < RT; i++)
+            for (int hf = 0; hf < NH; hf++) {
+                f32x4 acc[RT][JN];
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < RT; i++)
 #pragma unroll
-            for (int q = 0; q < KT_MID; q++)
+                    for (int j = 0; j < JN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++) {
-                    act8 af[RT], bfr[4];
+                for (int q = 0; q < KT_MID; q++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) {
+                        act8 af[RT], bfr[JN];
+#pragma unroll
+                        for (int i = 0; i < RT; i++) {
+                            const int m = (wr * RT + i) * 16 + frag_row;
+                            const int swz = MID == 64 ? ((m >> 1) & 7) : (m & 15);
+                            af[i] = *reinterpret_cast<const act8*>(T2 + m * MID + (((q * 8 + ks * 4 + frag_q) ^ swz) << 3));
+                        }
+                        const int slot = ((ks * 4 + frag_q) ^ ((frag_row >> 1) & 7)) * 8;
+#pragma unroll
+                        for (int j = 0; j < JN; j++)
+                            bfr[j] = *reinterpret_cast<const act8*>(BsC + q * 128 * 64 + ((wc * 4 + hf * JN + j) * 16 + frag_row) * 64 + slot);
+#pragma unroll
+                        for (int i = 0; i < RT; i++)
+#pragma unroll
+                            for (int j = 0; j < JN; j++)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+                if constexpr (NEXT) {
+                    if (hf == NH - 1) {
+                        // everyone is done with the Wc chunk (and, in the last chunk, with t2): the first Wd k-tile of this chunk lands in the Wc
+                        // buffer while the epilogue below runs; the last chunk brings both of its k-tiles, the second into the dead t2
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        asm volatile("s_barrier" ::: "memory");
+                        ISSUE_WD(2 * nc, BsC);
+                        if (nc == C4 / 128 - 1) ISSUE_WD(2 * nc + 1, T2);
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < JN; jj++) {
+                    const int j = hf * JN + jj;
+                    const int ncol = (wc * 4 + j) * 16 + 4 * frag_q;
+                    const float4 bias = *reinterpret_cast<const float4*>(p.bc + nc * 128 + ncol);
 #pragma unroll
                     for (int i = 0; i < RT; i++) {
                         const int m = (wr * RT + i) * 16 + frag_row;
-                        const int swz = MID == 64 ? ((m >> 1) & 7) : (m & 15);
-                        af[i] = *reinterpret_cast<const act8*>(T2 + m * MID + (((q * 8 + ks * 4 + frag_q) ^ swz) << 3));
+                        const uint2 r = resid[nc][i][j];   // (a pixel beyond the image's right edge holds zeros: its halo row was the zero page)
+                        const uint2 o = pack4<true>(amax, acc[i][jj] + vec4(bias) + vec4(r));
+                        if constexpr (NEXT) lds_write8(Cs + m * LDC + ncol, o);   // (typed: no compiler vmcnt(0) in front of it -- the Wd tile is in flight)
+                        else *reinterpret_cast<uint2*>(Cs + m * LDC + ncol) = o;
                     }
-                    const int slot = ((ks * 4 + frag_q) ^ ((frag_row >> 1) & 7)) * 8;
+                }
+            }
+            if constexpr (NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the Wd tile(s)
+            __syncthreads();
+            uint16_t* yimg = p.y + (long long)b * p.H * p.W * C4;
+            int tl = tid;
+            if constexpr (NEXT) asm volatile("" : "+v"(tl));   // (opaque: the store addresses are computed HERE, not hoisted above GEMM 1 and kept in registers -- or scratch -- across the kernel)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        bfr[j] = *reinterpret_cast<const act8*>(BsC + q * 128 * 64 + ((wc * 4 + j) * 16 + frag_row) * 64 + slot);
+            for (int it = 0; it < C_ITERS; it++) {
+                const int id = tl + it * BN_THREADS;
+                const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
+                const int oy = img_y(m >> 4, m & 15), ox = img_x(m >> 4, m & 15);
+                bool keep = ox < p.W && oy < p.H;
+                if constexpr (NEXT) keep = keep && (!p.y_even || (((oy | ox) & 1) == 0));
+                if (keep)
+                    store16_stream(yimg + ((long long)oy * p.W + ox) * C4 + nc * 128 + ch * 8, *reinterpret_cast<const uint4*>(Cs + m * LDC + ch * 8));
+            }
+            if constexpr (NEXT) {
+                if (nc == 0) {   // (zeroed here, not in front of the chunk loop: 32 registers that are not live through the first chunk's GEMM 3)
 #pragma unroll
                     for (int i = 0; i < RT; i++)
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < MIDN / 32; j++) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int ncol = (wc * 4 + j) * 16 + 4 * frag_q;
-                const float4 bias = *reinterpret_cast<const float4*>(p.bc + nc * 128 + ncol);
-#pragma unroll
-                for (int i = 0; i < RT; i++) {
-                    const int m = (wr * RT + i) * 16 + frag_row;
-                    uint2* cell = reinterpret_cast<uint2*>(Cs + m * LDC + ncol);
-                    const uint2 r = resid[nc][i][j];   // (a pixel beyond the image's right edge holds zeros: its halo row was the zero page)
-                    *cell = pack4<true>(amax, acc[i][j] + vec4(bias) + vec4(r));
+                GEMM4_KTILE(0, BsC);
+                if (nc == C4 / 128 - 1) {
+                    GEMM4_KTILE(64, T2);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");   // everyone is done with the first Wd k-tile
+                    ISSUE_WD(2 * nc + 1, BsC);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                    GEMM4_KTILE(64, BsC);
                 }
-            }
-            __syncthreads();
-            uint16_t* yimg = p.y + (long long)b * p.H * p.W * C4;
-#pragma unroll
-            for (int it = 0; it < C_ITERS; it++) {
-                const int id = tid + it * BN_THREADS;
-                const int m = id / CH_PER_ROW, ch = id % CH_PER_ROW;
-                const int oy = img_y(m >> 4, m & 15), ox = img_x(m >> 4, m & 15);
-                if (ox < p.W && oy < p.H)
-                    store16_stream(yimg + ((long long)oy * p.W + ox) * C4 + nc * 128 + ch * 8, *reinterpret_cast<const uint4*>(Cs + m * LDC + ch * 8));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __syncthreads();  // staging and Wc tile are reused by the next chunk
         }
+        if constexpr (NEXT) {
+            // t1' = relu(acc4 + bd): through the staging tile (free now), then 16-byte coalesced stores of whole 256-byte pixel rows
+#pragma unroll
+            for (int j = 0; j < MIDN / 32; j++) {
+                const int ncol = (wc * (MIDN / 32) + j) * 16 + 4 * frag_q;
+                const float4 bias = *reinterpret_cast<const float4*>(p.bd + ncol);
+#pragma unroll
+                for (int i = 0; i < RT; i++) {
+                    const int m = (wr * RT + i) * 16 + frag_row;
+                    *reinterpret_cast<uint2*>(Cs + m * LDC + ncol) = pack4<true>(amax, acc4[i][j] + vec4(bias));
+                }
+            }
+            __syncthreads();
+            uint16_t* timg = p.t1n + (long long)b * p.H * p.W * MIDN;
+            constexpr int CPR = MIDN / 8;
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+#pragma unroll
+            for (int it = 0; it < (MO * CPR) / BN_THREADS; it++) {
+                const int id = tl + it * BN_THREADS;
+                const int m = id / CPR, ch = id % CPR;
+                const int oy = img_y(m >> 4, m & 15), ox = img_x(m >> 4, m & 15);
+                if (ox < p.W && oy < p.H)
+                    store16_stream(timg + ((long long)oy * p.W + ox) * MIDN + ch * 8, *reinterpret_cast<const uint4*>(Cs + m * LDC + ch * 8));
+            }
+        }
+#undef ISSUE_WD
+#undef GEMM4_KTILE
     }
     report_range(p.status, amax);
 }
@@ -881,6 +990,8 @@ struct ResnetHandle {
     int chain_split = 1;                  // SALVE_RESNET_CHAIN_NO_SPLIT: the 8-wave form for the 256-channel shapes too
     int chain_dbg = 0, chain_waves = 8;   // chain_dbg: ablation build only (timing-only switches of expand_chain_kernel); SALVE_RESNET_CHAIN_16_WAVES
     std::vector<int> y_even;              // per op: 1 = the chained expand convolution stores only Y's even pixels (expand_chain.h: y_even_w)
+    std::vector<int> next;                // per op: 1 = this fused block also computes the op three further on (the next block's first 1x1 convolution:
+                                          //         bottleneck_kernel's NEXT form), 2 = ... and stores only the even pixels of its own output
     int no_transposed_tiles = 0;          // SALVE_RESNET_NO_TRANSPOSED_TILES: the fused blocks' fourth, half-empty tile column instead (bit-identity tests, A/B)
 };
 
@@ -1033,6 +1144,29 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
             if (dead) { h->fused[i] = shapes ? 1 : 2; i += 2; }
         }
     }
+    // (r6) The last fused block of layer 1 takes the following block's first convolution along (bottleneck_kernel's NEXT form): a 1x1 /
+    // stride 1 convolution with ReLU, 4 MID -> 2 MID channels, that reads the block's output Y and nothing else.  If Y's only other
+    // readers, up to the buffer's next writer, are stride-2 projection shortcuts, only its even pixels are stored.
+    h->next.assign(h->ops.size(), 0);
+    for (size_t i = 0; !(flags & SALVE_RESNET_NO_NEXT_FUSE) && i + 3 < h->ops.size(); i++) {
+        if (h->fused[i] != 1) continue;
+        const salve_resnet_op_t &a = h->ops[i], &c = h->ops[i + 2], &n = h->ops[i + 3];
+        const int mid = a.Cout;
+        const bool fits = n.op == SALVE_OP_CONV && n.KH == 1 && n.KW == 1 && n.stride == 1 && n.pad == 0 && n.relu && n.res_buf == SALVE_NO_BUF &&
+                          n.in2_buf == SALVE_NO_BUF && n.in_buf == c.out_buf && n.Cin == 4 * mid && n.Cout == 2 * mid && n.Hi == c.Ho && n.Wi == c.Wo &&
+                          n.out_buf >= 0 && n.out_buf != c.out_buf && n.out_buf != a.in_buf && !h->fused[i + 3];
+        if (!fits) continue;
+        bool even = !(flags & SALVE_RESNET_CHAIN_STORE_ALL) && c.Ho == c.Wo && !(c.Ho & 1), any = false;
+        for (size_t k = i + 4; even && k < h->ops.size(); k++) {
+            const salve_resnet_op_t& o = h->ops[k];
+            if (o.in_buf == c.out_buf || (o.op == SALVE_OP_CONV && o.res_buf == c.out_buf)) even = false;
+            if (o.op == SALVE_OP_CONV && o.in2_buf == c.out_buf) {
+                if (o.stride2 == 2 && o.Hi2 == c.Ho && o.Wi2 == c.Wo) any = true; else even = false;
+            }
+            if (o.op != SALVE_OP_AVGPOOL_FC && o.out_buf == c.out_buf) break;
+        }
+        h->next[i] = (even && any) ? 2 : 1;
+    }
     h->chain.assign(h->ops.size(), 0);
     {
         // 2 (default) = expand_chain_kernel wherever the shapes allow, chained with the next block's first convolution where
@@ -1169,11 +1303,18 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.tiles_t = strip ? (o.Hi + 15) / 16 : 0;
             const long long grid = (long long)batch * (a.tiles_x * a.tiles_y + a.tiles_t);
             if (grid > 0x7FFFFFFFll) { salve_fail("batch too large"); return SALVE_ERR_BAD_ARG; }
+            a.wd = nullptr; a.bd = nullptr; a.t1n = nullptr; a.y_even = 0;
+            const bool with_next = h->fused[oi] == 1 && narrow && h->next[oi];
+            if (with_next) {
+                const salve_resnet_op_t& on = h->ops[oi + 3];
+                a.wd = h->d_weights + on.w_off; a.bd = h->d_params + on.b_off; a.t1n = buf(on.out_buf); a.y_even = h->next[oi] == 2;
+            }
             if (h->fused[oi] == 2) hipLaunchKernelGGL((bottleneck_kernel<64, 8, true>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
+            else if (with_next) hipLaunchKernelGGL((bottleneck_kernel<64, 8, false, true>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
             else if (narrow) hipLaunchKernelGGL((bottleneck_kernel<64, 8>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
             else hipLaunchKernelGGL((bottleneck_kernel<128, 4>), dim3((unsigned)grid), dim3(BN_THREADS), 0, s, a);
             SALVE_HIP_CHECK(hipGetLastError());
-            oi += 2;
+            oi += with_next ? 3 : 2;
             continue;
         }
         if (o.op == SALVE_OP_CONV && h->chain[oi]) {

@@ -286,12 +286,17 @@ def test_fused_bottleneck_is_bit_identical_to_three_kernels():
     x = torch.randn(3, 224, 224, 8).to(torch.float16).to(DEV)
     x[..., 6:] = 0
     outs = []
-    for flags in (0, _lib.RESNET_NO_BLOCK_FUSE, _lib.RESNET_NO_PROJ_FUSE, _lib.RESNET_NO_TRANSPOSED_TILES):
+    for flags in (0, _lib.RESNET_NO_BLOCK_FUSE, _lib.RESNET_NO_PROJ_FUSE, _lib.RESNET_NO_TRANSPOSED_TILES, _lib.RESNET_NO_NEXT_FUSE,
+                  _lib.RESNET_CHAIN_STORE_ALL):
         eng = hip_resnet.HipResNet(model.state_dict(), 50, torch.device(DEV), flags=flags)
-        outs.append(eng.forward_nhwc(x).clone())
-        torch.cuda.synchronize()
+        for rep in range(2):
+            if eng._ws is not None:
+                eng._ws[: eng._ws.numel() & ~1].view(torch.int16).fill_(0x7E00)   # fp16 NaNs: a pixel left unwritten (Y's odd pixels) must never be read
+            o = eng.forward_nhwc(x).clone()
+            torch.cuda.synchronize()
+        outs.append(o)
     assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 def _run_program(bld, x_nhwc, flags, read_bufs):
@@ -326,12 +331,14 @@ def _run_program(bld, x_nhwc, flags, read_bufs):
     return out
 
 
-@pytest.mark.parametrize("H,W,B", [(56, 56, 3), (24, 40, 2), (16, 24, 5), (32, 48, 2)])
+@pytest.mark.parametrize("H,W,B", [(56, 56, 3), (24, 40, 2), (16, 24, 5), (32, 48, 2), (24, 24, 37)])
 def test_fused_block_outputs_are_bit_identical_tensor_for_tensor(H, W, B):
     """The two fused 56 x 56 block forms (projection block, plain block) against the three-kernel path, the whole OUTPUT TENSOR of each
     block, for the default tiling -- the strip of 8 columns right of the whole 16-column tiles covered by TRANSPOSED tiles of 16 rows x 8
     columns (56 = 3 x 16 + 8; 40 = 2 x 16 + 8 with a half-empty last transposed tile at H = 24; 24 = 16 + 8) -- and for the tiling with a
-    half-empty last tile column (SALVE_RESNET_NO_TRANSPOSED_TILES); W = 48 has no strip.  GEMM 2 of a transposed tile walks the taps in
+    half-empty last tile column (SALVE_RESNET_NO_TRANSPOSED_TILES); W = 48 has no strip.  The plain block is followed by the next stage's
+    first block, so that it runs in the NEXT form (the following 1x1 convolution as its fourth GEMM, Y stored at even pixels only where its
+    one other reader is a stride-2 shortcut: the square cases), against SALVE_RESNET_NO_NEXT_FUSE and SALVE_RESNET_CHAIN_STORE_ALL.  GEMM 2 of a transposed tile walks the taps in
     the image's (dy, dx) order, so every pixel is the same sum in the same order: bits must agree, and no output pixel may stay unwritten
     (the activation buffers start as fp16 NaNs)."""
     g = torch.Generator().manual_seed(H * 100 + W)
@@ -348,15 +355,27 @@ def test_fused_block_outputs_are_bit_identical_tensor_for_tensor(H, W, B):
     bld.conv(rnd(64, 256, 1, 1, s=0.08), rnd(64, s=0.1), 3, 1, NB, H, W, 1, 0, True)
     bld.conv(rnd(64, 64, 3, 3, s=0.06), rnd(64, s=0.1), 1, 2, NB, H, W, 1, 1, True)
     bld.conv(rnd(256, 64, 1, 1, s=0.12), rnd(256, s=0.1), 2, 4, 3, H, W, 1, 0, True)
+    # the next block's first convolution (1x1, 256 -> 128, same resolution): bottleneck_kernel's NEXT form computes it as a fourth GEMM on Y ...
+    bld.conv(rnd(128, 256, 1, 1, s=0.08), rnd(128, s=0.1), 4, 1, NB, H, W, 1, 0, True)
+    # ... and the rest of that down-sampling block: 3x3 / stride 2, then the last 1x1 with the stride-2 projection shortcut reading Y (buffer 4)
+    Ho, Wo = bld.conv(rnd(128, 128, 3, 3, s=0.04), rnd(128, s=0.1), 1, 2, NB, H, W, 2, 1, True)
+    bld.conv1x1_with_shortcut(rnd(512, 128, 1, 1, s=0.1), rnd(512, s=0.1), 2, 0, Ho, Wo, rnd(512, 256, 1, 1, s=0.06), rnd(512, s=0.1), 4, H, W, 2)
     x = rnd(B, H, W, 64).to(torch.float16)
-    read = {3: (H, W, 256), 4: (H, W, 256)}
+    read = {3: (H, W, 256), 4: (H, W, 256), 1: (H, W, 128), 0: (Ho, Wo, 512)}
+    NAN = 0x7E00
     ref = _run_program(bld, x, _lib.RESNET_NO_BLOCK_FUSE, read)
-    assert not (ref[3] == 0x7E00).any() and not (ref[4] == 0x7E00).any()
-    assert (ref[4] != 0).float().mean() > 0.2, "the test block should not be dead"
-    for flags in (0, _lib.RESNET_NO_TRANSPOSED_TILES, _lib.RESNET_ROUND_ROBIN_TILES):
+    assert not any((ref[i] == NAN).any() for i in read)
+    assert (ref[4] != 0).float().mean() > 0.2 and (ref[1] != 0).float().mean() > 0.2, "the test blocks should not be dead"
+    T, N, A = _lib.RESNET_NO_TRANSPOSED_TILES, _lib.RESNET_NO_NEXT_FUSE, _lib.RESNET_CHAIN_STORE_ALL
+    for flags in (0, T, N, A, T | A, T | N, _lib.RESNET_ROUND_ROBIN_TILES):
         got = _run_program(bld, x, flags, read)
-        for i in (3, 4):
-            bad = (got[i] != ref[i]).any(-1)
+        even_only = not (flags & (N | A)) and H == W    # Y's one other reader samples it at stride 2: only those pixels are stored
+        for i in read:
+            g_, r_ = got[i], ref[i]
+            if i == 4 and even_only:
+                assert (g_[:, 1::2] == NAN).all() and (g_[:, :, 1::2] == NAN).all(), "odd pixels of Y were meant to stay unwritten"
+                g_, r_ = g_[:, ::2, ::2], r_[:, ::2, ::2]
+            bad = (g_ != r_).any(-1)
             assert not bad.any(), f"flags {flags}, buffer {i}: {int(bad.sum())} pixels differ, first at {bad.nonzero()[0].tolist()}"
 
 
@@ -370,7 +389,7 @@ def test_unknown_flag_bits_are_refused():
     wb, pr, kt = np.concatenate(bld.weights).astype(np.int16), np.concatenate(bld.params).astype(np.float32), np.concatenate(bld.ktab).astype(np.int32)
     mk = lambda flags: lib.salve_resnet_create(0, 64, ops.ctypes.data_as(ctypes.c_void_p), 1, wb.ctypes.data_as(ctypes.c_void_p), wb.nbytes,
                                                pr.ctypes.data_as(ctypes.c_void_p), pr.nbytes, kt.ctypes.data_as(ctypes.c_void_p), kt.size, flags)
-    assert not mk(4096) and b"unknown bit" in lib.salve_last_error()
+    assert not mk(8192) and b"unknown bit" in lib.salve_last_error()
     h = mk(_lib.RESNET_NO_TRANSPOSED_TILES | _lib.RESNET_CHAIN_STORE_ALL)
     assert h
     lib.salve_resnet_destroy(ctypes.c_void_p(h))
