@@ -189,6 +189,9 @@ def gemm_probe(dev, device_index: int, seconds: float = 2.5):
     return out
 
 
+COPY_WGS_PER_CU, COPY_MODE = 64, 1   # launch shape of the copy kernel: the best of tools/measure/copy_sweep.py (non-temporal, 4 loads in flight, 64 workgroups per CU: 5.3 TB/s; torch copy_ 4.9)
+
+
 def copy_probe(dev, gbytes: float = 4.0, iters: int = 20):
     """HBM copy rate of this box: a float4 device-to-device copy of 4 GB, bytes read + bytes written per second.  The kernel is the
     measurement helper of tests/native (a grid-stride float4 copy, 8 workgroups per CU; not part of the product library); where that
@@ -203,13 +206,13 @@ def copy_probe(dev, gbytes: float = 4.0, iters: int = 20):
     if helper.exists():
         try:
             lib = ctypes.CDLL(str(helper))
-            lib.salve_debug_copy16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int32, ctypes.c_void_p]
+            lib.salve_debug_copy16.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
             lib.salve_debug_copy16.restype = ctypes.c_int
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             stream = lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
             def fn():
-                if lib.salve_debug_copy16(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), n, 8 * cus, stream()) != 0:
+                if lib.salve_debug_copy16(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), n, COPY_WGS_PER_CU * cus, COPY_MODE, stream()) != 0:
                     raise RuntimeError("salve_debug_copy16 failed")
             what = "float4 grid-stride copy kernel (tests/native/testhelp.hip)"
         except (OSError, AttributeError):

@@ -7,5 +7,6 @@ extern "C" {
 // with the rasteriser (tools/debug_overlap2.py, tests/test_gpu_rasteriser.py: the packed-fp32 regression test).
 int salve_debug_burn(int32_t blocks, int32_t iters, int32_t mode, float* sink, void* stream);
 // float4 device copy of n16 16-byte lanes on `blocks` workgroups of 256 threads: bench.py's HBM copy microbenchmark (measurement only).
-int salve_debug_copy16(void* dst, const void* src, long long n16, int32_t blocks, void* stream);
+// mode: bit 0 = non-temporal loads / stores, bit 1 = 8 (instead of 4) loads in flight per thread.
+int salve_debug_copy16(void* dst, const void* src, long long n16, int32_t blocks, int32_t mode, void* stream);
 }

@@ -41,22 +41,37 @@ __global__ __launch_bounds__(256) void burn_kernel(int iters, int mode, float* s
 }
 
 // float4 device copy: the HBM copy microbenchmark of bench.py ("confirm the HBM peak with a copy microbenchmark on the
-// box").  Grid-stride over 16-byte lanes, four independent loads in flight per thread before the stores.
-__global__ __launch_bounds__(256) void copy16_kernel(float4* __restrict__ dst, const float4* __restrict__ src, long long n16) {
+// box").  Grid-stride over 16-byte lanes, U independent loads in flight per thread before the stores; NT: non-temporal loads and stores
+// (a copy re-uses nothing: the lines need not stay in the L2 / memory-side cache).
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void copy16_kernel(f32x4* __restrict__ dst, const f32x4* __restrict__ src, long long n16) {
     const long long stride = (long long)gridDim.x * 256;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride); else dst[i + u * stride] = v[u];
+        }
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 }  // namespace
 
-extern "C" int salve_debug_copy16(void* dst, const void* src, long long n16, int32_t blocks, void* stream) {
+// mode: bit 0 = non-temporal accesses, bit 1 = 8 instead of 4 loads in flight per thread
+extern "C" int salve_debug_copy16(void* dst, const void* src, long long n16, int32_t blocks, int32_t mode, void* stream) {
     if (!dst || !src || n16 <= 0 || blocks <= 0) return -1;
-    hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(dst),
-                       reinterpret_cast<const float4*>(src), n16);
+    f32x4* d = reinterpret_cast<f32x4*>(dst);
+    const f32x4* s = reinterpret_cast<const f32x4*>(src);
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode & 3) {
+        case 0: hipLaunchKernelGGL((copy16_kernel<4, false>), dim3(blocks), dim3(256), 0, st, d, s, n16); break;
+        case 1: hipLaunchKernelGGL((copy16_kernel<4, true>), dim3(blocks), dim3(256), 0, st, d, s, n16); break;
+        case 2: hipLaunchKernelGGL((copy16_kernel<8, false>), dim3(blocks), dim3(256), 0, st, d, s, n16); break;
+        default: hipLaunchKernelGGL((copy16_kernel<8, true>), dim3(blocks), dim3(256), 0, st, d, s, n16); break;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
