@@ -489,6 +489,7 @@ def main() -> None:
         scat_ms, dens_ms = mean_ms("scatter"), mean_ms("densify")
         ras_ms = scat_ms + dens_ms
         achieved = renders * bpr / (ras_ms * 1e-3) / 1e9
+        tile_bytes = 224 * 224 * (2 * (pipe.engine.in_channels // S) + 4)   # per render: its share of the fp16 NHWC sample + the u8x4 second image
         vfull = [(a.elapsed_time(b), r) for a, b, r in vev if r == full_n]
         ver_ms = float(np.mean([t for t, _ in vfull]))
         gflop = GFLOP_PER_SAMPLE[(args.layers, 6 * S)]
@@ -513,12 +514,15 @@ def main() -> None:
             # the rasteriser as a whole (splat + densify): SURVEY 8d's bytes per render x the renders of one launch /
             # the summed average durations of those launches (HIP events on the launching streams).  The pose-independent
             # panorama index (bev_pano_index_kernel, once per panorama set at load_panos) is outside the step, like the uploads.
-            "roofline": {"kernel": "rasteriser: bev_splat_kernel + bev_densify_kernel", "bound": "hbm",
+            "roofline": {"kernel": "rasteriser: bev_splat_kernel + bev_densify_kernel (whose last phase writes the verifier tiles since round 6: salve_bev_densify_tiles)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": None if ras_traffic is None else int(ras_traffic * renders),
                          "traffic_raw_fetch": None if ras_traffic_raw is None else int(ras_traffic_raw * renders), "traffic_source": ras_src,
                          "launch_ms": round(ras_ms, 3), "scatter_ms": round(scat_ms, 3), "densify_ms": round(dens_ms, 3),
                          "launches_timed": len(vfull), "renders_per_launch": renders, "algorithmic_bytes_per_render": bpr,
+                         # the tile phase rides in densify_ms; its own bytes (fp16 NHWC sample written, pretiled second image read) are NOT in
+                         # SURVEY 8d's figure and not in `achieved`: with them the same launches move this many GB/s
+                         "tile_bytes_per_render": tile_bytes, "achieved_with_tile_bytes": round(renders * (bpr + tile_bytes) / (ras_ms * 1e-3) / 1e9, 3),
                          # the bound that BINDS the dominant kernel (bev_densify_kernel): VALU busy share of the SIMD cycles and vector /
                          # scalar wave-instructions per render, from the SQ counter pass at this launch shape (null: no pass at this shape)
                          "valu_busy": None if issue is None else issue.get("valu_busy"),

@@ -39,7 +39,7 @@ typedef enum {
                                      sparse image into out_bev (no key image in memory, salve_bev_workspace_init is gone), salve_resnet_create
                                      takes its kernel selection as `flags` -- the library reads no environment variable;
                                      6: SALVE_RESNET_CHAIN_STORE_ALL / _NO_TRANSPOSED_TILES / _NO_NEXT_FUSE, out_flags bit 4 (renders densified in the
-                                     given order), a launch of >= 1025 renders keeps its dispatch order in the workspace's key image; unknown
+                                     given order), salve_bev_densify_tiles, a launch of >= 1025 renders keeps its dispatch order in the workspace's key image; unknown
                                      `flags` / `out_flags` bits are refused with SALVE_ERR_BAD_ARG (ABI 5 ignored them) */
 
 /* Device status word: an optional device int32 the caller zeroes once and passes to the launches below.  Kernels OR bits
@@ -254,6 +254,19 @@ int salve_bev_tiles(const uint32_t* bev, int32_t bev_h, int32_t bev_w, const sal
 int salve_bev_tile_pairs(const uint32_t* bev_a, const uint32_t* bev_b, int32_t bev_h, int32_t bev_w, const salve_tile_job_t* jobs_a,
                          const salve_tile_job_t* jobs_b, int32_t n_pairs, const int32_t* coef_y, const int32_t* coef_x, int32_t resize,
                          int32_t crop, const float* lut, void* out, int32_t out_c, int32_t b_pretiled, void* stream);
+
+/* salve_bev_densify followed by salve_bev_tile_pairs(..., b_pretiled = 1) as ONE launch (the fused render -> verify driver's form since
+ * ABI 6): every workgroup of the densify kernel, having finished its render, resizes / crops / normalises it into the verifier's sample
+ * while the image is still in the L2 -- a launch of its own reads the 1 MB image back from HBM.  The job tables are indexed by RENDER
+ * of the launch (render r = image r of out_bev):
+ *   jobs_a[r]   .slot / .chan: destination sample and first channel of render r's tile (.bev_offset is not used); slot < 0: no tile
+ *   jobs_b[r]   the pair's second image: .bev_offset = element offset of a SALVE_TILE_U8X4 image inside tiles_b, .chan its first channel
+ *               (the two chans are the halves of one group of six, as for salve_bev_tile_pairs)
+ * out_bev holds the complete images afterwards, exactly as after salve_bev_densify; `out` the same bits salve_bev_tile_pairs writes.
+ * (bev_rendering_utils.py:254-328 + train_utils.py:126-159 / transform.py:256-272, 386-420, 105-123, 177-202.) */
+int salve_bev_densify_tiles(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, const salve_tile_job_t* jobs_a, const salve_tile_job_t* jobs_b,
+                            const uint32_t* tiles_b, const int32_t* coef_y, const int32_t* coef_x, int32_t resize, int32_t crop, const float* lut,
+                            void* out, int32_t out_c, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Verifier: early-fusion ResNet forward pass (fp16 MFMA, fp32 accumulation).

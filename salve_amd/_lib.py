@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "salve_layout_rasterise",
     "salve_bev_tiles",
     "salve_bev_tile_pairs",
+    "salve_bev_densify_tiles",
     "salve_resize_rgb_u8",
     "salve_resnet_create",
     "salve_resnet_destroy",
@@ -130,6 +131,8 @@ def load() -> ctypes.CDLL:
     lib.salve_bev_tiles.restype = ctypes.c_int
     lib.salve_bev_tile_pairs.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
     lib.salve_bev_tile_pairs.restype = ctypes.c_int
+    lib.salve_bev_densify_tiles.argtypes = [ctypes.POINTER(BevConfig), i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, sz, vp]
+    lib.salve_bev_densify_tiles.restype = ctypes.c_int
     lib.salve_resize_rgb_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp]
     lib.salve_resize_rgb_u8.restype = ctypes.c_int
     lib.salve_resnet_create.argtypes = [i32, i32, vp, i32, vp, sz, vp, sz, vp, sz, i32]

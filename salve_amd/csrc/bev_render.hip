@@ -293,6 +293,39 @@ __device__ __forceinline__ void wg_barrier_after_global_stores() {
     __syncthreads();
 }
 
+// ---- the verifier's input tile (salve_hip.h: salve_bev_tiles) -- shared by the tile kernels below and by the densify kernel's phase H
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }  // |values| < 3: no saturation needed
+__device__ __forceinline__ void tile_pixel(const uint32_t* __restrict__ img, int W, const int4 cy, const int4 cx, const float* __restrict__ lut, float v[3]) {
+    const uint32_t p00 = img[(size_t)cy.x * W + cx.x], p01 = img[(size_t)cy.x * W + cx.y];
+    const uint32_t p10 = img[(size_t)cy.y * W + cx.x], p11 = img[(size_t)cy.y * W + cx.y];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const int a = (p00 >> (8 * ch)) & 255, b = (p01 >> (8 * ch)) & 255;
+        const int cc = (p10 >> (8 * ch)) & 255, d = (p11 >> (8 * ch)) & 255;
+        const int S0 = a * cx.z + b * cx.w;  // horizontal pass, x2048
+        const int S1 = cc * cx.z + d * cx.w;
+        int r = (((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2;
+        r = min(max(r, 0), 255);
+        v[ch] = lut[ch * 256 + r];
+    }
+}
+
+
+// (r6) salve_bev_densify_tiles: the arguments of the tile phase, read by bev_densify_kernel from the workspace (behind order[] in the key
+// image) instead of as kernel arguments -- the kernel runs at the limit of the scalar register file, and every live scalar pair moves
+// spill reloads into its hot loops (tools/densify_spills.py).  Written by bev_tile_fuse_kernel in front of the densify launch.
+struct TileFuse {
+    const salve_tile_job_t* jobs_a;   // [n] per RENDER of the launch: destination sample and channel (bev_offset unused: the image is the render's own)
+    const salve_tile_job_t* jobs_b;   // [n] per render: the pair's second image -- element offset into tiles_b -- and its channel
+    const uint32_t* tiles_b;          // SALVE_TILE_U8X4 images
+    const int32_t* coef_y;
+    const int32_t* coef_x;
+    const float* lut;
+    uint16_t* out;
+    int32_t resize, crop, out_c, reserved;
+};
+__global__ void bev_tile_fuse_kernel(TileFuse t, TileFuse* dst) { *dst = t; }
+
 // Apex candidates of short edges (star_table.h): built once per process on the host with the exact predicates.
 __device__ SdTable d_star_table;
 
@@ -327,6 +360,9 @@ __host__ __device__ inline size_t bitmap_words_hw(int H, int W) {
     return (size_t)2 * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H) * TILE_H * TILE_WORDS;
 }
 constexpr int DENSIFY_ORDERED = 256;      // DensifyCfg::out_flags, set by bev_stage only: order[] is valid
+constexpr int DENSIFY_TILES = 512;        // ... a TileFuse block is valid: phase H writes the render's verifier tile
+// the key image of a launch of n renders: int32 cost[n], int32 order[n], then (16-byte aligned) the TileFuse block
+__host__ __device__ inline size_t tile_fuse_word(size_t n) { return (2 * n + 3) & ~(size_t)3; }
 constexpr int ORDER_BINS = 1024;
 constexpr int ORDER_MIN_RENDERS = 1025;   // more than two rounds of the 512 resident workgroups.  Measured (tools/densify_order_threshold.py, costly
                                           // first against as given): 1536 ... 4096 renders -2.2 ... -6.9 % on the box and the noisy scene; at 640 / 768 /
@@ -725,6 +761,93 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
             bev[pixi(x, y)] = 0u;
         }
     }
+    // ---- phase H (salve_bev_densify_tiles): the render's verifier tile -- Resize (11-bit taps) -> centre crop -> ToTensor -> Normalize of
+    //      THIS image and of the pair's pretiled second image, whole 6-channel groups into the fp16 NHWC sample: what
+    //      bev_tile_pair_kernel does in a launch of its own, which reads the 1 MB image back from HBM after the whole launch has gone by;
+    //      here it comes out of the L2 it was just written to.  The taps and the normalisation table go into the LDS of the (dead) bitmaps.
+    if (c.out_flags & DENSIFY_TILES) {
+        wg_barrier_after_global_stores();                 // phase G's stores have left the CU (and everyone is done with the bitmaps)
+        asm volatile("buffer_inv sc1" ::: "memory");      // the CU's L1 may hold lines of the image as they were BEFORE this workgroup wrote them
+        const TileFuse* tfp = reinterpret_cast<const TileFuse*>(reinterpret_cast<const int32_t*>(bitmaps_all + (size_t)gridDim.x * bitmap_words_hw(H, W)) + tile_fuse_word(gridDim.x));
+        const TileFuse tf = *tfp;
+        const salve_tile_job_t ja = tf.jobs_a[rid], jb = tf.jobs_b[rid];
+        if (ja.slot >= 0) {
+            int4* cy_l = reinterpret_cast<int4*>(smem);
+            int4* cx_l = cy_l + tf.resize;
+            float* lut_l = reinterpret_cast<float*>(cx_l + tf.resize);
+            for (int i = tid; i < tf.resize; i += DENSIFY_THREADS) {
+                cy_l[i] = reinterpret_cast<const int4*>(tf.coef_y)[i];
+                cx_l[i] = reinterpret_cast<const int4*>(tf.coef_x)[i];
+            }
+            for (int i = tid; i < 3 * 256; i += DENSIFY_THREADS) lut_l[i] = tf.lut[i];
+            __syncthreads();
+            const int crop = tf.crop, off = (tf.resize - crop) / 2, out_c = tf.out_c;
+            const bool a_first = ja.chan < jb.chan;
+            const int c0 = a_first ? ja.chan : jb.chan;
+            const uint32_t* tb = tf.tiles_b + jb.bev_offset;
+            uint16_t* osample = tf.out + (size_t)ja.slot * crop * crop * out_c;
+            // A thread keeps ONE tile column (its two source columns and their weights stay in registers) and walks the rows: no division per
+            // pixel, the row's taps are a broadcast LDS read.  Columns in groups of 256 lanes (crop = 224: 32 idle lanes per group), the
+            // DENSIFY_THREADS / 256 groups take the rows in turn.  24-bit multiplies (full rate; the tile kernels' v_mul_lo_u32 are quarter
+            // rate): every product here is < 2^28 of operands < 2^16 -- the same integers.
+            constexpr int COLS = 256, RGROUPS = DENSIFY_THREADS / COLS;
+            for (int j0 = 0; j0 < crop; j0 += COLS) {
+                const int j = j0 + (tid & (COLS - 1));
+                if (j >= crop) continue;
+                const int4 cx = cx_l[j + off];
+                // U rows at a time: all their gathers (the image out of the L2, the second image's pixel) are issued before the first is used --
+                // one row after the other the phase was a chain of dependent round trips, 112 per thread (+1.0 ms per 4096 renders)
+                constexpr int U = 4;
+                for (int i0 = tid / COLS; i0 < crop; i0 += RGROUPS * U) {
+                    int4 cy[U];
+                    uint32_t p00[U], p01[U], p10[U], p11[U], q[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int i = min(i0 + u * RGROUPS, crop - 1);
+                        cy[u] = cy_l[i + off];
+                        const uint32_t* r0 = bev + __umul24(cy[u].x, W);
+                        const uint32_t* r1 = bev + __umul24(cy[u].y, W);
+                        p00[u] = r0[cx.x]; p01[u] = r0[cx.y]; p10[u] = r1[cx.x]; p11[u] = r1[cx.y];
+                        q[u] = tb[i * crop + j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int i = i0 + u * RGROUPS;
+                        if (i >= crop) break;
+                        const int idx = i * crop + j;
+                        float va[3], vb[3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            const uint32_t a = (p00[u] >> (8 * ch)) & 255u, b = (p01[u] >> (8 * ch)) & 255u;
+                            const uint32_t cc = (p10[u] >> (8 * ch)) & 255u, d = (p11[u] >> (8 * ch)) & 255u;
+                            const int S0 = (int)(__umul24(a, cx.z) + __umul24(b, cx.w));   // horizontal pass, x2048 (tile_pixel, op for op)
+                            const int S1 = (int)(__umul24(cc, cx.z) + __umul24(d, cx.w));
+                            int r = (int)(((__umul24(cy[u].z, S0 >> 4) >> 16) + (__umul24(cy[u].w, S1 >> 4) >> 16) + 2u) >> 2);
+                            r = min(max(r, 0), 255);
+                            va[ch] = lut_l[ch * 256 + r];
+                            vb[ch] = lut_l[ch * 256 + ((q[u] >> (8 * ch)) & 255u)];
+                        }
+                        const float* lo = a_first ? va : vb;
+                        const float* hi = a_first ? vb : va;
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        const uint32_t w0 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){lo[0], lo[1]}, h2));   // (round to nearest even, as (_Float16)f)
+                        const uint32_t w1 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){lo[2], hi[0]}, h2));
+                        const uint32_t w2 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){hi[1], hi[2]}, h2));
+                        uint16_t* px = osample + (size_t)idx * out_c;
+                        if (out_c == 8) {
+                            *reinterpret_cast<uint4*>(px) = make_uint4(w0, w1, w2, 0u);
+                        } else {
+                            uint32_t* o = reinterpret_cast<uint32_t*>(px + c0);
+                            o[0] = w0; o[1] = w1; o[2] = w2;
+                            if (c0 + 12 > out_c)
+                                for (int k = c0 + 6; k < out_c; k += 2) *reinterpret_cast<uint32_t*>(px + k) = 0u;
+                        }
+                    }
+                }
+            }
+        }
+    }
     if (dbg_mask) {
         for (int i = tid; i < H * W; i += DENSIFY_THREADS) {
             const int y = i / W, x = i % W;
@@ -744,7 +867,6 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ tiles
-__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }  // |values| < 3: no saturation needed
 
 __global__ __launch_bounds__(256) void bev_tile_kernel(const uint32_t* __restrict__ bev, int W,
                                                        const salve_tile_job_t* __restrict__ jobs,
@@ -789,21 +911,6 @@ __global__ __launch_bounds__(256) void bev_tile_kernel(const uint32_t* __restric
 }
 
 // One tile pixel of image `img`: cv2 INTER_LINEAR on uint8 with 11-bit taps, then the normalisation LUT (bev_tile_kernel's arithmetic).
-__device__ __forceinline__ void tile_pixel(const uint32_t* __restrict__ img, int W, const int4 cy, const int4 cx, const float* __restrict__ lut, float v[3]) {
-    const uint32_t p00 = img[(size_t)cy.x * W + cx.x], p01 = img[(size_t)cy.x * W + cx.y];
-    const uint32_t p10 = img[(size_t)cy.y * W + cx.x], p11 = img[(size_t)cy.y * W + cx.y];
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-        const int a = (p00 >> (8 * ch)) & 255, b = (p01 >> (8 * ch)) & 255;
-        const int cc = (p10 >> (8 * ch)) & 255, d = (p11 >> (8 * ch)) & 255;
-        const int S0 = a * cx.z + b * cx.w;  // horizontal pass, x2048
-        const int S1 = cc * cx.z + d * cx.w;
-        int r = (((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2;
-        r = min(max(r, 0), 255);
-        v[ch] = lut[ch * 256 + r];
-    }
-}
-
 // Both tiles of an early-fusion pair per thread, six channels (plus the sample's zero padding behind its last group) in
 // whole-pixel stores: see salve_bev_tile_pairs in salve_hip.h.
 __global__ __launch_bounds__(256) void bev_tile_pair_kernel(const uint32_t* __restrict__ bev_a, const uint32_t* __restrict__ bev_b, int W,
@@ -1089,7 +1196,7 @@ static bool orders_renders(const DevCfg& d, int n, size_t npx) {
 static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* pano_rgb, const uint16_t* pano_depth,
                      int32_t n_panos, const double* sphere, const void* pano_index, const salve_bev_hyp_t* hyps, int32_t n, uint32_t* out_bev,
                      int16_t* dbg_img_xy, uint64_t* dbg_keys, uint8_t* dbg_mask, int32_t* dbg_stats, int32_t* in_window,
-                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream, const TileFuse* tiles = nullptr) {
     DevCfg d;
     if (!make_devcfg(cfg, &d)) return SALVE_ERR_BAD_ARG;
     if (n == 0) return SALVE_OK;
@@ -1149,6 +1256,13 @@ static int bev_stage(const salve_bev_config_t* cfg, int stages, const uint8_t* p
             SALVE_HIP_CHECK(hipGetLastError());
             dc.out_flags |= DENSIFY_ORDERED;
         }
+        if (tiles) {   // salve_bev_densify_tiles: the tile phase's arguments go into the key image behind order[] (TileFuse)
+            if ((tile_fuse_word((size_t)n) * sizeof(int32_t) + sizeof(TileFuse)) > npx * sizeof(uint32_t)) { salve_fail("too many renders for the fused tile phase"); return SALVE_ERR_BAD_ARG; }
+            if ((size_t)tiles->resize * 2 * sizeof(int4) + 3 * 256 * sizeof(float) > (size_t)d.H * d.wpr * sizeof(uint32_t)) { salve_fail("resize too large for the fused tile phase"); return SALVE_ERR_UNSUPPORTED; }
+            hipLaunchKernelGGL(bev_tile_fuse_kernel, dim3(1), dim3(1), 0, s, *tiles, reinterpret_cast<TileFuse*>(reinterpret_cast<int32_t*>(ws.keys) + tile_fuse_word((size_t)n)));
+            SALVE_HIP_CHECK(hipGetLastError());
+            dc.out_flags |= DENSIFY_TILES;
+        }
         if (dbg_mask || dbg_stats || d.dbg_flags) {   // development outputs or flags: the instantiation that has them
             const int st = ensure_lds(bev_densify_kernel<true>, lds, attr[1], mu);
             if (st != SALVE_OK) return st;
@@ -1186,6 +1300,17 @@ int salve_bev_densify(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_be
                       int32_t* dbg_stats, int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
     return bev_stage(cfg, 2, nullptr, nullptr, 0, nullptr, nullptr, nullptr, n, out_bev, nullptr, nullptr, dbg_mask, dbg_stats,
                      nullptr, status, workspace, workspace_bytes, stream);
+}
+
+int salve_bev_densify_tiles(const salve_bev_config_t* cfg, int32_t n, uint32_t* out_bev, const salve_tile_job_t* jobs_a, const salve_tile_job_t* jobs_b,
+                            const uint32_t* tiles_b, const int32_t* coef_y, const int32_t* coef_x, int32_t resize, int32_t crop, const float* lut,
+                            void* out, int32_t out_c, int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n == 0) return SALVE_OK;
+    if (!jobs_a || !jobs_b || !tiles_b || !coef_y || !coef_x || !lut || !out) { salve_fail("salve_bev_densify_tiles: null pointer"); return SALVE_ERR_BAD_ARG; }
+    if (crop <= 0 || resize < crop || out_c < 6 || out_c % 2 != 0) { salve_fail("salve_bev_densify_tiles: need 0 < crop <= resize, even out_c >= 6"); return SALVE_ERR_BAD_ARG; }
+    const TileFuse t = {jobs_a, jobs_b, tiles_b, coef_y, coef_x, lut, reinterpret_cast<uint16_t*>(out), resize, crop, out_c, 0};
+    return bev_stage(cfg, 2, nullptr, nullptr, 0, nullptr, nullptr, nullptr, n, out_bev, nullptr, nullptr, nullptr, nullptr, nullptr, status, workspace,
+                     workspace_bytes, stream, &t);
 }
 
 // Utility paths: key image 0 -> sparse image + bitmaps of render 0 (the emission of bev_splat_kernel).

@@ -93,7 +93,7 @@ class RenderVerifyPipeline:
     LAUNCH_HBM_FRACTION = 0.5   # of the HBM that is free when the pipeline is created: BEV + tile + rasteriser + activation workspaces of one launch
 
     def __init__(self, model, device: torch.device, pano_hw: Tuple[int, int] = (512, 1024), chunk: Optional[int] = None,
-                 overlap: bool = True, streams: int = 3, n_hypotheses: Optional[int] = None) -> None:
+                 overlap: bool = True, streams: int = 3, n_hypotheses: Optional[int] = None, fuse_tiles: bool = True) -> None:
         """chunk: hypotheses per render / verify launch.  None (default): chosen by `pick_launch` from the HBM that is free now --
         the whole shard of `n_hypotheses` rows in one launch if its workspaces fit LAUNCH_HBM_FRACTION of it (a shard of 4096
         hypotheses needs 57 GB with one surface / ResNet-50, 80 GB with two / ResNet-152, of 288), else the fewest equal launches."""
@@ -102,6 +102,9 @@ class RenderVerifyPipeline:
         # not raised later by this pipeline's check() under the wrong name
         status.check(self.device, "a launch issued before this RenderVerifyPipeline was created")
         self.model = model
+        # fuse_tiles (default): the densify kernel writes every render's verifier tile itself (salve_bev_densify_tiles); False: densify, then
+        # salve_bev_tile_pairs in a launch of its own (the form of rounds 2-5; same bits: tests/test_gpu_rasteriser.py)
+        self.fuse_tiles = bool(fuse_tiles)
         self.surfaces = surfaces_for(model.modalities)
         self.has_layout = "layout" in set(model.modalities)
         self.engine = model.compiled(self.device)
@@ -229,6 +232,17 @@ class RenderVerifyPipeline:
             jobs2_chan.append(6 * si + 3 * (1 - swap))
         # job tables are stored hypothesis-major so that a chunk is a contiguous slice
         st = lambda parts: np.stack(parts, 1).reshape(-1) if parts else np.zeros(0, dtype=np.int64)   # (layout only: no texture jobs)
+        # the same jobs indexed by RENDER of a chunk's launch (salve_bev_densify_tiles): render rslot * S + si of its chunk is pair
+        # (slot, si); stored chunk after chunk, a chunk's renders contiguous
+        rj_slot = np.full(N * S, -1, dtype=np.int64)
+        rj_chan_a, rj_chan_b, rj_ident = np.zeros(N * S, dtype=np.int64), np.zeros(N * S, dtype=np.int64), np.zeros(N * S, dtype=np.int64)
+        base = (j // self.chunk) * self.chunk * S      # first render of the hypothesis's chunk
+        for si in range(S):
+            r = base + rslot * S + si
+            rj_slot[r] = slot
+            rj_chan_a[r] = 6 * si + 3 * swap
+            rj_chan_b[r] = 6 * si + 3 * (1 - swap)
+            rj_ident[r] = hyp.i2.astype(np.int64) * S + si
         prepared = {
             "n": N,
             "i2": np.asarray(hyp.i2).astype(np.int64),
@@ -236,6 +250,8 @@ class RenderVerifyPipeline:
             "rows": self.ras.upload_hypotheses(rows),
             "jobs1": self.ras.upload_tile_jobs(st(jobs1_bev), st(jobs1_slot), st(jobs1_chan)),
             "jobs2": self.ras.upload_tile_jobs(st(jobs2_bev), st(jobs2_slot), st(jobs2_chan), pretiled=True),
+            "rjobs_a": self.ras.upload_tile_jobs(np.zeros(N * S, dtype=np.int64), rj_slot, rj_chan_a),
+            "rjobs_b": self.ras.upload_tile_jobs(rj_ident, rj_slot, rj_chan_b, pretiled=True),
             "in_window": torch.zeros(N * S, dtype=torch.int32, device=self.device),  # posed renders IN RENDER ORDER, filled by score()
             "ready": torch.cuda.Event(),   # the tables are on the device: launches on other streams wait for it
         }
@@ -293,13 +309,18 @@ class RenderVerifyPipeline:
             self.ras.ws_slot = slot
             _, e1 = self._timed(timers, n * S, "densify")  # benchmark: HIP events on the stream the kernel is launched on
             with tracing.range("salve.densify"):
-                self.ras.densify(n * S, bev)
+                if self.fuse_tiles:   # the render's tile leaves the densify kernel itself, while the image is in the L2
+                    self.ras.densify_tiles(n * S, bev, prepared["rjobs_a"][lo * S * jb:], prepared["rjobs_b"][lo * S * jb:], self.ref_tiles, tiles,
+                                           self.engine.in_channels)
+                else:
+                    self.ras.densify(n * S, bev)
             if e1 is not None:
                 e1.record()
-            with tracing.range("salve.tiles"):
-                # (jobs1[k] / jobs2[k] are the two halves of one surface's six channels of one sample: prepare())
-                self.ras.tile_pairs(bev, prepared["jobs1"][lo * S * jb:], self.ref_tiles, prepared["jobs2"][lo * S * jb:], n * S, tiles,
-                                    self.engine.in_channels, pretiled=True)
+            if not self.fuse_tiles:
+                with tracing.range("salve.tiles"):
+                    # (jobs1[k] / jobs2[k] are the two halves of one surface's six channels of one sample: prepare())
+                    self.ras.tile_pairs(bev, prepared["jobs1"][lo * S * jb:], self.ref_tiles, prepared["jobs2"][lo * S * jb:], n * S, tiles,
+                                        self.engine.in_channels, pretiled=True)
         if self.has_layout:
             with tracing.range("salve.layout"):
                 lbev = self.layout_bevs[buf]

@@ -225,6 +225,19 @@ class BevRasteriser:
         _lib.check(st, "salve_bev_densify")
         return out_bev
 
+    def densify_tiles(self, n: int, out_bev: torch.Tensor, jobs_a: torch.Tensor, jobs_b: torch.Tensor, tiles_b: torch.Tensor, out: torch.Tensor,
+                      out_c: int) -> torch.Tensor:
+        """`densify` + `tile_pairs(pretiled=True)` as ONE launch (include/salve_hip.h: salve_bev_densify_tiles): every render's workgroup writes
+        its verifier tile as soon as the image is complete.  `jobs_a` / `jobs_b` (upload_tile_jobs, the second with pretiled=True) are indexed by
+        RENDER of the launch: destination sample and channel of render r / the pair's pretiled second image and its channel."""
+        ws = self._workspace(n)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            st = self.lib.salve_bev_densify_tiles(ctypes.byref(self.cfg), n, p(out_bev), p(jobs_a), p(jobs_b), p(tiles_b), p(self.coef_y), p(self.coef_x),
+                                                  self.resize, self.crop, p(self.lut), p(out), out_c, status.ptr(self.device), p(ws), ws.numel(), self._stream())
+        _lib.check(st, "salve_bev_densify_tiles")
+        return out_bev
+
     def render_counted(self, pano_rgb: torch.Tensor, pano_depth: torch.Tensor, hyps_dev: torch.Tensor, n: int,
                        out_bev: torch.Tensor, counts: torch.Tensor) -> None:
         """`render` that also reports, per render, how many points fell inside the window (int32 [n])."""

@@ -133,3 +133,42 @@ def test_full_size_properties():
     # two ranks' shards reproduce the single-rank logits
     parts = [pipe.score(pipe.prepare(table.shard(r, 2))).clone() for r in range(2)]
     assert torch.equal(torch.cat(parts), a)
+
+
+@pytest.mark.parametrize("modalities,layers,N,chunk", [
+    (["floor_rgb_texture"], 18, 70, 32),                                   # one surface: 16-byte pixels, a partly filled last chunk
+    (["ceiling_rgb_texture", "floor_rgb_texture"], 18, 37, 37),            # two surfaces: 12-byte groups of a 32-byte pixel, the padding channels zeroed
+    (["floor_rgb_texture"], 18, 1100, 1100),                               # a launch in costly-first order (>= 1025 renders): tiles follow the render, not the workgroup id
+])
+def test_tiles_from_the_densify_kernel_equal_the_tile_kernel(modalities, layers, N, chunk):
+    """salve_bev_densify_tiles (the densify kernel writes every render's verifier tile in its last phase, from the L2) against the two-launch
+    form salve_bev_densify + salve_bev_tile_pairs: the tile buffer, the BEV images and the logits must agree bit for bit -- same integer
+    taps, same table, same whole-group stores; only who reads the image differs.  Tile buffers start as NaNs: every sample's pixels, padding
+    channels included, must be written by the fused phase exactly where the tile kernel writes them."""
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+    from salve_amd.pipeline import RenderVerifyPipeline
+
+    dev = torch.device("cuda:0")
+    P = 6
+    panos = [synthetic.make_pano(i, scene="cluttered" if i % 2 else "box") for i in range(P)]
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(layers, False, 2, SimpleNamespace(modalities=modalities)).eval()
+    synthetic.trained_looking_batchnorm(model)
+    table = synthetic.make_hypotheses(N, P, seed=3)
+    table.t[5] = 40.0           # a render with no point inside the window: an empty image still makes a (normalised-zero) tile in both forms
+    outs = []
+    for fuse in (True, False):
+        pipe = RenderVerifyPipeline(model, dev, chunk=chunk, overlap=False, streams=1, fuse_tiles=fuse)
+        pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
+        prep = pipe.prepare(table)
+        pipe.tile_bufs[0].view(torch.int16).fill_(0x7E00)
+        logits = pipe.score(prep).clone()
+        torch.cuda.synchronize()
+        pipe.check("fused tiles test")
+        last = N - (N - 1) // chunk * chunk          # samples of the last chunk: what the buffers hold now
+        outs.append((logits, pipe.tile_bufs[0][:last].clone(), pipe.bevs[0][: last * len(pipe.surfaces)].clone(), pipe.valid_mask(prep)))
+        del pipe
+    (la, ta, ba, va), (lb, tb, bb, vb) = outs
+    assert torch.isfinite(ta.float()).all(), "a pixel of the sample was not written by the fused phase"
+    assert torch.equal(ta.view(torch.int16), tb.view(torch.int16))
+    assert torch.equal(ba, bb) and torch.equal(la, lb) and (va == vb).all() and not va[5]

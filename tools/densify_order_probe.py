@@ -41,7 +41,21 @@ for lo in range(0, N, 256):
     b1[lo:lo + 256] = (occ & (nb < 4)).flatten(1).sum(1).cpu().numpy()      # a 4-neighbour missing
     b2[lo:lo + 256] = (occ & (nb <= 2)).flatten(1).sum(1).cpu().numpy()     # two or more missing
     b3[lo:lo + 256] = (occ & (nb8 <= 3)).flatten(1).sum(1).cpu().numpy()    # five or more of the eight missing
-feat = {"sites": sites, "sites with a 4-neighbour missing": b1, "sites with >= 2 4-neighbours missing": b2, "sites with >= 5 of 8 neighbours missing": b3}
+# (r6) the number the verdict's split launch would order by: the HARD-SITE count of every render (what is left after the lean walks, phase E1),
+# read from the development statistics of a densify pass over the same scatter (stats[6]); a split stage -- launch A = phases B .. E1 + F,
+# an order kernel on these counts, launch B = E2 + G -- can be no better than ordering the ONE launch by them, which is what is timed below
+import ctypes
+from salve_amd import status
+stats = torch.zeros((N, 8), dtype=torch.int32, device=dev)
+ws = pipe.ras._workspace(N)
+scratch = pipe.bevs[0].clone()
+st = pipe.ras.lib.salve_bev_densify(ctypes.byref(pipe.ras.cfg), N, ctypes.c_void_p(scratch.data_ptr()), None, ctypes.c_void_p(stats.data_ptr()), status.ptr(dev),
+                                    ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+assert st == 0
+torch.cuda.synchronize()
+hard = stats[:, 6].cpu().numpy().astype(np.float64)
+del scratch
+feat = {"HARD sites (true count after E1)": hard, "sites": sites, "sites with a 4-neighbour missing": b1, "sites with >= 2 4-neighbours missing": b2, "sites with >= 5 of 8 neighbours missing": b3}
 feat = {k: v[prep["rank"]] for k, v in feat.items()}   # render order -> hypothesis order
 for k, v in feat.items():
     print(f"{k}: min {v.min():.0f} median {np.median(v):.0f} max {v.max():.0f}")
@@ -49,6 +63,8 @@ rng = np.random.default_rng(0)
 orders = {"by panorama (product)": None, "in-window descending": np.argsort(-inw, kind="stable"), "random": rng.permutation(N)}
 for k, v in feat.items():
     orders[k + ", descending"] = np.argsort(-v, kind="stable")
+for wgt in (0.01, 0.03):
+    orders[f"hard + {wgt} sites, descending"] = np.argsort(-(feat["HARD sites (true count after E1)"] + wgt * feat["sites"]), kind="stable")
 orders["b2 + 0.05 sites, descending"] = np.argsort(-(feat["sites with >= 2 4-neighbours missing"] + 0.05 * feat["sites"]), kind="stable")
 for wgt in (2, 4, 8):
     orders[f"b1 + {wgt} b3, descending"] = np.argsort(-(feat["sites with a 4-neighbour missing"] + wgt * feat["sites with >= 5 of 8 neighbours missing"]), kind="stable")
