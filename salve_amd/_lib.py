@@ -13,7 +13,7 @@ import numpy as np
 
 import os
 
-# SALVE_HIP_LIB: development override (ablation builds of tools/build_ablations.sh); the product loads the in-tree library
+# SALVE_HIP_LIB: development override (ablation builds of tools/probe/build_ablations.sh); the product loads the in-tree library
 LIB_PATH = Path(os.environ.get("SALVE_HIP_LIB") or (Path(__file__).resolve().parent / "libsalve_hip.so"))
 
 SALVE_OK = 0

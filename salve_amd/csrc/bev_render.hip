@@ -313,7 +313,7 @@ __device__ __forceinline__ void tile_pixel(const uint32_t* __restrict__ img, int
 
 // (r6) salve_bev_densify_tiles: the arguments of the tile phase, read by bev_densify_kernel from the workspace (behind order[] in the key
 // image) instead of as kernel arguments -- the kernel runs at the limit of the scalar register file, and every live scalar pair moves
-// spill reloads into its hot loops (tools/densify_spills.py).  Written by bev_tile_fuse_kernel in front of the densify launch.
+// spill reloads into its hot loops (tools/measure/densify_spills.py).  Written by bev_tile_fuse_kernel in front of the densify launch.
 struct TileFuse {
     const salve_tile_job_t* jobs_a;   // [n] per RENDER of the launch: destination sample and channel (bev_offset unused: the image is the render's own)
     const salve_tile_job_t* jobs_b;   // [n] per render: the pair's second image -- element offset into tiles_b -- and its channel
@@ -348,7 +348,7 @@ static int ensure_star_table() {
 // ---- longest renders first (r5).  A launch of n renders is n / 512 rounds of resident workgroups, dispatched in the order of their
 // ids; renders differ in cost, and the launch ends with a tail in which CUs run dry behind the last, arbitrary renders.  With the
 // costly renders dispatched first the tail is made of cheap ones: densify -4 ... -5 % on every synthetic scene (box 14.04 -> 13.32 ms
-// per 4096, cluttered 19.24 -> 18.43, noisy 20.12 -> 19.64 with the order made on the host; tools/densify_order_probe.py), identical images -- renders are independent.
+// per 4096, cluttered 19.24 -> 18.43, noisy 20.12 -> 19.64 with the order made on the host; tools/probe/densify_order_probe.py), identical images -- renders are independent.
 // The cost estimate is a count the splat makes from a tile's occupancy words while they are in its LDS (bev_splat.h: emit_tile): sites with two or more of their four
 // neighbours missing (outline and isolated sites: the ones whose walks are long; the plain site or point count does not predict the
 // cluttered / noisy scenes, and of five such counts this one was good on all three scenes).
@@ -364,7 +364,7 @@ constexpr int DENSIFY_TILES = 512;        // ... a TileFuse block is valid: phas
 // the key image of a launch of n renders: int32 cost[n], int32 order[n], then (16-byte aligned) the TileFuse block
 __host__ __device__ inline size_t tile_fuse_word(size_t n) { return (2 * n + 3) & ~(size_t)3; }
 constexpr int ORDER_BINS = 1024;
-constexpr int ORDER_MIN_RENDERS = 1025;   // more than two rounds of the 512 resident workgroups.  Measured (tools/densify_order_threshold.py, costly
+constexpr int ORDER_MIN_RENDERS = 1025;   // more than two rounds of the 512 resident workgroups.  Measured (tools/probe/densify_order_threshold.py, costly
                                           // first against as given): 1536 ... 4096 renders -2.2 ... -6.9 % on the box and the noisy scene; at 640 / 768 /
                                           // 1024 renders -7 ... +4 % with either sign (1024 = exactly two rounds: +3.5 % box, config 5's launches +5 %)
 
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
     __shared__ int list_wave_total[DENSIFY_THREADS / 64];
     // (bev_order_kernel: the costly renders first.  The order array lies behind the bitmaps of the launch's renders -- the workspace's
     //  key image: [cost n][order n] -- and is named by a flag bit instead of a pointer argument: one more live scalar register pair moved
-    //  eight spill reloads into the lean-walk loop, tools/densify_spills.py)
+    //  eight spill reloads into the lean-walk loop, tools/measure/densify_spills.py)
     int rid = blockIdx.x;
     if (c.out_flags & DENSIFY_ORDERED) {
         // order[] = the second int32 array of the workspace's key image, which carve_workspace puts behind the bitmaps of the launch's n = gridDim.x

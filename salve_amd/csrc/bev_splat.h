@@ -31,7 +31,7 @@ constexpr int BLK_W = 16, BLK_H = 4;        // panorama block = one wavefront: l
 #endif
 constexpr int SPLAT_BATCH = SPLAT_BATCH_N;  // blocks a wavefront keeps in flight (loads of all of them issued before any is used)
 // (The timing-only switches of this kernel -- cull only / no block loop / no emission / no LDS atomic / no loads -- are a patch,
-// tools/ablations/timing_switches.patch, applied by tools/splat_ablation.sh: the product source carries none.)
+// tools/probe/ablations/timing_switches.patch, applied by tools/probe/splat_ablation.sh: the product source carries none.)
 
 // Block grid of a panorama: nbr block rows x (gpr groups of 64 block columns); entry (br, g, j) is block column 64 g + j.
 struct PanoGrid {

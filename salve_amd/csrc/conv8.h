@@ -29,7 +29,7 @@ constexpr int C8_THREADS = 512;
 constexpr int C8_BM = 256, C8_BN = 256, C8_KS = 64;
 constexpr int C8_HALF_E = 128 * C8_KS;   // uint16 elements of a half-tile
 
-// (timing-only builds -- no MFMAs / no fills / fills never waited for: tools/ablations/timing_switches.patch)
+// (timing-only builds -- no MFMAs / no fills / fills never waited for: tools/probe/ablations/timing_switches.patch)
 #define C8_MFMA(B_, A_, C_) { C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(B_, A_, C_, 0, 0, 0); }
 
 template <bool POINTWISE, bool SRC2>

@@ -351,8 +351,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvArgs p)
     }
 }
 
-#ifdef SALVE_BUILD_ABLATIONS   // the measured-and-rejected wide-tile kernels d / e / f: tools/build_ablations.sh only
-#include "../../tools/ablations/conv_wide.h"
+#ifdef SALVE_BUILD_ABLATIONS   // the measured-and-rejected wide-tile kernels d / e / f: tools/probe/build_ablations.sh only
+#include "../../tools/probe/ablations/conv_wide.h"
 #endif
 #include "conv8.h"
 #include "stem_pool.h"
@@ -480,7 +480,7 @@ struct BottleneckArgs {
 constexpr int BN_THREADS = 512;  // 8 waves: two workgroups per CU give 4 waves per SIMD to hide the many short phases
 
 // 16-byte store of an output that nobody reads before the next launch.  (Cache-policy bits on it -- sc1, nt, sc0 sc1, sc1 nt -- were
-// timed in round 4 and change nothing; the timing-only builds of this file are tools/ablations/timing_switches.patch.)
+// timed in round 4 and change nothing; the timing-only builds of this file are tools/probe/ablations/timing_switches.patch.)
 __device__ __forceinline__ void store16_stream(uint16_t* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 
 // PROJ: the first block of layer 1 -- its input has MID channels (not 4 MID) and its shortcut is a 1x1 projection, which rides
@@ -1002,7 +1002,7 @@ static bool expand_shape(int mid) { return mid == 128 || mid == 256; }   // (512
 // SALVE_CONV_WIDE (read when a handle is created): unset = the 8-phase 256 x 256 kernel (conv8.h) on the compute-bound shapes
 // that fit it, 0 = conv_igemm_kernel everywhere, 8 = the 8-phase kernel wherever it fits.  d | e | f select the wide-tile /
 // split-role kernels of conv_wide.h, which were measured per shape on MI355X and rejected: they exist
-// only in the ablation build (-DSALVE_BUILD_ABLATIONS, tools/build_ablations.sh) -- the product library treats them as 0.
+// only in the ablation build (-DSALVE_BUILD_ABLATIONS, tools/probe/build_ablations.sh) -- the product library treats them as 0.
 // All of them are bit-identical to conv_igemm_kernel (same k order, same fp32 accumulation).
 enum { WIDE_OFF = 0, WIDE_256_K64_S2 = 4, WIDE_128_K64_S1 = 5, WIDE_PC_128 = 6, WIDE_8PHASE = 7, WIDE_AUTO = 8 };
 
@@ -1082,7 +1082,7 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
     {
         // default: the 8-phase kernel on the compute-bound shapes that fit it, in launches large enough for it
         int mode = (flags & SALVE_RESNET_CONV_IGEMM_ONLY) ? WIDE_OFF : ((flags & SALVE_RESNET_CONV8_WHEREVER) ? WIDE_8PHASE : WIDE_AUTO);
-#ifdef SALVE_BUILD_ABLATIONS   // development build only: the rejected wide-tile kernels d / e / f of tools/ablations/conv_wide.h
+#ifdef SALVE_BUILD_ABLATIONS   // development build only: the rejected wide-tile kernels d / e / f of tools/probe/ablations/conv_wide.h
         if (const char* e = getenv("SALVE_CONV_WIDE")) mode = e[0] == 'd' ? WIDE_256_K64_S2 : (e[0] == 'e' ? WIDE_128_K64_S1 : (e[0] == 'f' ? WIDE_PC_128 : mode));
 #endif
         h->wide_auto = mode == WIDE_AUTO;
@@ -1387,7 +1387,7 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             while ((1 << a.cin_log2) < o.Cin) a.cin_log2++;
             // (the 256 x 256 tiles of the 8-phase kernel are a quarter as many workgroups, one per CU: small launches stay on
             //  conv_igemm_kernel -- the results are bit-identical either way)
-            // Measured on ResNet-50 (tools/bench_resnet.py): +1 % for the whole forward at batch 4096, -1 % at 2048 and below
+            // Measured on ResNet-50 (tools/measure/bench_resnet.py): +1 % for the whole forward at batch 4096, -1 % at 2048 and below
             // (one workgroup per CU: a launch of fewer than six rounds loses more in its last round than the kernel gains).
             const bool few_tiles = h->wide[oi] == WIDE_8PHASE && h->wide_auto && ((M + 255) / 256) * (long long)(o.Cout / 256) < 1536;
             if (h->wide[oi] != WIDE_OFF && !few_tiles) {

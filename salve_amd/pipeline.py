@@ -208,7 +208,7 @@ class RenderVerifyPipeline:
         i1 = np.asarray(hyp.i1).astype(np.int64)
         if order is None:
             order, rank = render_order(i1, self.chunk)  # rank[j]: position of hypothesis j in the render order of the whole table
-        else:   # development (tools/densify_order_probe.py): a caller's render order; it must keep every hypothesis inside its chunk
+        else:   # development (tools/probe/densify_order_probe.py): a caller's render order; it must keep every hypothesis inside its chunk
             order = np.asarray(order).astype(np.int64)
             assert sorted(order.tolist()) == list(range(N)) and bool((order // self.chunk == np.arange(N) // self.chunk).all())
             rank = np.empty(N, dtype=np.int64)

@@ -145,6 +145,12 @@ class BevRasteriser:
         if idx is not None and idx[1] == (pano_depth.data_ptr(), P, pano_depth._version):
             return idx[0]
         assert pano_depth.is_contiguous() and tuple(pano_depth.shape[1:]) == self.pano_hw and pano_depth.element_size() == 2
+        if idx is not None:
+            # REPLACING an index (the depth maps were written in place): launches issued earlier -- possibly on other streams, the pipeline runs its
+            # scatter on one of its own -- may still read the old buffer, and the caching allocator hands its memory out again as soon as the last
+            # reference goes, ordered against the current stream only.  Rare (as rare as overwriting depth maps): wait for the device, as the
+            # workspace-growth path does.
+            torch.cuda.synchronize(self.device)
         nbytes = self.lib.salve_bev_pano_index_bytes(ctypes.byref(self.cfg), P)
         if nbytes == 0:
             _lib.check(-1, "salve_bev_pano_index_bytes")

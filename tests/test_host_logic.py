@@ -417,3 +417,30 @@ def test_pick_launch_prefers_the_whole_shard_and_cuts_into_equal_whole_rounds():
         pick_launch(0, 14 * MB, 1 << 40)
     # a shard with more than 1024 renders is not cut into launches of 1024 or fewer while memory allows more
     assert pick_launch(4096, 14 * MB, 3000 * 14 * MB) * 1 > 1024
+
+
+def test_every_recorded_experiment_patch_applies_to_its_base_commit(tmp_path):
+    """tools/probe/ablations/*.patch are records of measured experiments, pinned to the commit they were made against (MANIFEST.json): each
+    must dry-run-apply to that commit's tree (after the patches it builds on), and every patch in the directory must be in the manifest --
+    so none of them can rot silently.  Needs the git history (this container; skipped where the tree travels without .git)."""
+    import json
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    abl = root / "tools" / "probe" / "ablations"
+    man = json.loads((abl / "MANIFEST.json").read_text())
+    assert sorted(p.name for p in abl.glob("*.patch")) == sorted(man["patches"]), "a patch without a manifest entry (or the reverse)"
+    if not (root / ".git").exists():
+        pytest.skip("no git history here")
+    base = tmp_path / "base"
+    base.mkdir()
+    tar = subprocess.run(["git", "-C", str(root), "archive", man["base_commit"]], capture_output=True, check=True).stdout
+    subprocess.run(["tar", "-x", "-C", str(base)], input=tar, check=True)
+    for name, e in man["patches"].items():
+        work = tmp_path / ("w_" + name)
+        subprocess.run(["cp", "-r", str(base), str(work)], check=True)
+        for pre in e["after"]:
+            subprocess.run(["patch", "-p1", "-s", "-i", str(abl / pre)], cwd=work, check=True, capture_output=True)
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-i", str(abl / name)], cwd=work, capture_output=True, text=True)
+        assert r.returncode == 0, f"{name} does not apply to {man['base_commit']}: {r.stdout[-400:]}"

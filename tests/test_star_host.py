@@ -159,11 +159,11 @@ def test_sites_left_out_of_the_list_own_unit_triangles_only(lib):
 
 
 def test_the_walk_counter_tool_builds_and_reproduces_the_triangulation(tmp_path):
-    """tools/host/walk_counters.cpp (development: the general walk's counters with the kernel's E2 schedule simulated) compiles against
+    """tools/probe/host/walk_counters.cpp (development: the general walk's counters with the kernel's E2 schedule simulated) compiles against
     the kernel's headers as they are, and its simulated schedule -- eight wavefronts, runs of eight, delayed cache visibility -- emits
     the oracle's triangles for a realistic site set."""
     exe = tmp_path / "walk_counters"
-    subprocess.run(["g++", "-O2", "-o", str(exe), str(ROOT / "tools" / "host" / "walk_counters.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-o", str(exe), str(ROOT / "tools" / "probe" / "host" / "walk_counters.cpp")], check=True)
     hyp = synthetic.make_hypotheses(16, 2, seed=0)
     p0 = synthetic.make_pano(0)
     a = bo.xyzrgb_from_arrays(p0[1], p0[0], bo.floor_ceiling_z_range("floor"))
