@@ -1,14 +1,14 @@
 #!/bin/bash
-# Round 5: per-launch HBM traffic (FETCH_SIZE / WRITE_SIZE), L2 hit rate and SQ counters of ONE verifier forward, each counter set in a
+# Per-launch HBM traffic (FETCH_SIZE / WRITE_SIZE), L2 hit rate and SQ counters of ONE verifier forward, each counter set in a
 # rocprofv3 pass of its own (--kernel-trace only, the program directly after --).
-#   usage: gpu_r5_traffic.sh [batch = 4096] [layers = 50] [out = r5traffic_v50]
+#   usage: gpu_verifier_traffic.sh [batch = 4096] [layers = 50] [out = r6traffic_v50]
 set -u
 export TMPDIR=/tmp
-B=${1:-4096}; L=${2:-50}; TAG=${3:-r5traffic_v$L}
+B=${1:-4096}; L=${2:-50}; TAG=${3:-r6traffic_v$L}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 step() { local secs=$1 log=$2; shift 2; echo "== $*" >> "$OUT/steps.log"; timeout -k 10 "$secs" "$@" > "$OUT/$log" 2>&1; local rc=$?; echo "   rc=$rc" >> "$OUT/steps.log"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo TIMEOUT | tee -a "$OUT/steps.log"; exit 1; fi; return 0; }
-T="$GRAFT_REPO_ROOT/tools/trace_resnet.py"
+T="$GRAFT_REPO_ROOT/tools/measure/trace_resnet.py"
 cd /tmp
 step 300 trace.log rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python3 $T $B "$OUT/ops.json" $L && \
 step 300 pmc_f.log rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $T $B "$OUT/ops.json" $L && \
@@ -18,4 +18,4 @@ step 300 pmc_sq.log rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 step 300 pmc_clk.log rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_clk" -- python3 $T $B "$OUT/ops.json" $L
 find "$OUT" -name "*.db" -delete
 cat "$OUT/steps.log"
-python3 "$GRAFT_REPO_ROOT/tools/resnet_traffic_report.py" "$OUT" $B "round 5, MI355X, ResNet-$L" > "$OUT/report.md" 2> "$OUT/report.err"; tail -60 "$OUT/report.md" | cut -c1-220; tail -5 "$OUT/report.err"
+python3 "$GRAFT_REPO_ROOT/tools/measure/resnet_traffic_report.py" "$OUT" $B "round 6, MI355X, ResNet-$L" > "$OUT/report.md" 2> "$OUT/report.err"; tail -60 "$OUT/report.md" | cut -c1-220; tail -5 "$OUT/report.err"

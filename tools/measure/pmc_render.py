@@ -20,6 +20,18 @@ order = np.argsort(hyp.i1, kind="stable")                  # ... in panorama ord
 sid = [0 if v == "floor" else 1 for v in surfs]
 hd = ras.upload_hypotheses(pack_hypotheses(np.repeat(hyp.i1[order], S), np.tile(sid, n // S), np.repeat(hyp.R[order], S, axis=0),
                                            np.repeat(hyp.t[order], S, axis=0), np.ones(n)))
+# The rasteriser as the pipeline launches it since round 6: the scatter stage, then the densify stage whose last phase writes every render's
+# verifier tile (salve_bev_densify_tiles): render r -> sample r // S, channel group r % S; the pair's second image = a pretiled image per panorama.
+crop = ras.crop
+in_c = 8 * S
+bev = torch.empty((n, *ras.bev_hw), dtype=torch.int32, device=dev)
+tiles_b = torch.zeros((P * S, crop, crop), dtype=torch.int32, device=dev)
+tiles = torch.zeros((n // S, crop, crop, in_c), dtype=torch.float16, device=dev)
+r = np.arange(n)
+jobs_a = ras.upload_tile_jobs(np.zeros(n, dtype=np.int64), r // S, 6 * (r % S))
+jobs_b = ras.upload_tile_jobs(np.repeat(hyp.i2[order], S) * S + (r % S), r // S, 6 * (r % S) + 3, pretiled=True)
 for _ in range(2):
-    ras.render(d_rgb, d_depth, hd, n)
+    ras.scatter(d_rgb, d_depth, hd, n, bev)
+    ras.densify_tiles(n, bev, jobs_a, jobs_b, tiles_b, tiles, in_c)
 torch.cuda.synchronize()
+ras.check("pmc_render")

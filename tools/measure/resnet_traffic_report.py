@@ -1,4 +1,4 @@
-"""Per-launch roofline table of one verifier forward from gpurun_out/r3traffic (tools/archive/gpu_r3_traffic.sh).
+"""Per-launch roofline table of one verifier forward from the counter passes of tools/measure/gpu_verifier_traffic.sh.
 
 For every launch of the LAST of the three forwards: duration (kernel trace, no counters), algorithmic FLOP and bytes of the
 ops it executes (activations in + residual + out, fp16; weights once), the two roofline times (FLOP / 2.5 PFLOP/s dense fp16
@@ -59,10 +59,14 @@ print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 oi = 0
 tot = collections.Counter()
 for i, (name, us) in enumerate(launches):
-    take = 3 if "bottleneck" in name else (2 if ("stem_pool" in name or ("expand_chain" in name and ", true" in name)) else 1)
+    nxt = "bottleneck" in name and name.rstrip().endswith("false, true>")   # the NEXT form: the block + the following block's first 1x1 convolution
+    take = 4 if nxt else 3 if "bottleneck" in name else (2 if ("stem_pool" in name or ("expand_chain" in name and ", true" in name)) else 1)
     mine = ops[oi:oi + take]; oi += take
     fl = sum(op_cost(o)[0] for o in mine) * B
-    if take == 3:    # fused block: input + residual (the same tensor: once) + output
+    if take == 4:    # NEXT form: input, a quarter of Y (even pixels: its one other reader is a stride-2 shortcut), t1' out
+        a, c, n_ = mine[0], mine[2], mine[3]
+        by = (a["Hi"] * a["Wi"] * a["Cin"] * 2 + (c["Ho"] // 2) * (c["Wo"] // 2) * c["Cout"] * 2 + n_["Ho"] * n_["Wo"] * n_["Cout"] * 2) * B
+    elif take == 3:    # fused block: input + residual (the same tensor: once) + output
         a, c = mine[0], mine[2]
         by = (a["Hi"] * a["Wi"] * a["Cin"] * 2 + c["Ho"] * c["Wo"] * c["Cout"] * 2) * B
     elif take == 2 and "expand_chain" in name:  # expand + residual + next reduce: t2 and X in, Y and t1' out (Y is not read back)
