@@ -43,8 +43,31 @@ if __name__ == "__main__":
     d_rgb, d_depth = ras.upload_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
     h = pack_hypotheses(hyp.i1, surf, hyp.R, hyp.t, np.ones(N))
     bad = 0
+    # (r6) reps 1 and 2 run the pipeline's form: scatter, then the densify stage whose last phase writes the verifier tile (salve_bev_densify_tiles);
+    # every 16th render's tile is compared with the oracle's Resize -> Crop -> Normalize of ITS image (fp16-rounded), the second image being zeros
+    from oracle import bev_oracle as bo
+    crop = ras.crop
+    tiles_b = torch.zeros((1, crop, crop), dtype=torch.int32, device=dev)
+    r_ = np.arange(N)
+    jobs_a = ras.upload_tile_jobs(np.zeros(N, dtype=np.int64), r_, np.zeros(N, dtype=np.int64))
+    jobs_b = ras.upload_tile_jobs(np.zeros(N, dtype=np.int64), r_, np.full(N, 3, dtype=np.int64), pretiled=True)
+    tiles = torch.zeros((N, crop, crop, 8), dtype=torch.float16, device=dev)
+    bad_tiles = 0
     for rep in range(3):   # repeated: the triangle cache and the work distribution are timing dependent
-        bev = ras.render(d_rgb, d_depth, ras.upload_hypotheses(h), N)[0]
+        hd = ras.upload_hypotheses(h)
+        if rep == 0:
+            bev = ras.render(d_rgb, d_depth, hd, N)[0]
+        else:
+            bev = torch.empty((N, *ras.bev_hw), dtype=torch.int32, device=dev)
+            ras.scatter(d_rgb, d_depth, hd, N, bev)
+            ras.densify_tiles(N, bev, jobs_a, jobs_b, tiles_b, tiles, 8)
+            tg = tiles[::16, :, :, :3].float().cpu().numpy()
+            for k, j in enumerate(range(0, N, 16)):
+                exp = ref[j] if ref[j] is not None else np.zeros((501, 501, 3), np.uint8)
+                want = bo.tile_from_bev(exp).astype(np.float16).astype(np.float32).transpose(1, 2, 0)
+                if not np.array_equal(tg[k], want):
+                    bad_tiles += 1
+                    print("TILE MISMATCH rep", rep, "render", j, flush=True)
         got = ras.export_u8(bev).cpu().numpy()
         for j in range(N):
             exp = ref[j] if ref[j] is not None else np.zeros((501, 501, 3), np.uint8)
@@ -53,5 +76,5 @@ if __name__ == "__main__":
                 print("MISMATCH rep", rep, "render", j, jobs[j][:2], int((got[j] != exp).any(-1).sum()), "pixels", flush=True)
     from salve_amd import status
     status.check(dev, "parity_sweep")
-    print(f"scene {scene}, panoramas {hw[1]}x{hw[0]}, seed {seed}: renders compared:", 3 * N, "mismatches:", bad)
-    sys.exit(1 if bad else 0)
+    print(f"scene {scene}, panoramas {hw[1]}x{hw[0]}, seed {seed}: renders compared:", 3 * N, "mismatches:", bad, "; tiles of the fused phase compared:", 2 * len(range(0, N, 16)), "mismatches:", bad_tiles)
+    sys.exit(1 if (bad or bad_tiles) else 0)
