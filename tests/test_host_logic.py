@@ -433,14 +433,21 @@ def test_every_recorded_experiment_patch_applies_to_its_base_commit(tmp_path):
     assert sorted(p.name for p in abl.glob("*.patch")) == sorted(man["patches"]), "a patch without a manifest entry (or the reverse)"
     if not (root / ".git").exists():
         pytest.skip("no git history here")
-    base = tmp_path / "base"
-    base.mkdir()
-    tar = subprocess.run(["git", "-C", str(root), "archive", man["base_commit"]], capture_output=True, check=True).stdout
-    subprocess.run(["tar", "-x", "-C", str(base)], input=tar, check=True)
+    bases = {}
+
+    def tree_of(commit):
+        if commit not in bases:
+            d = tmp_path / ("base_" + commit)
+            d.mkdir()
+            tar = subprocess.run(["git", "-C", str(root), "archive", commit], capture_output=True, check=True).stdout
+            subprocess.run(["tar", "-x", "-C", str(d)], input=tar, check=True)
+            bases[commit] = d
+        return bases[commit]
+
     for name, e in man["patches"].items():
         work = tmp_path / ("w_" + name)
-        subprocess.run(["cp", "-r", str(base), str(work)], check=True)
+        subprocess.run(["cp", "-r", str(tree_of(e.get("base", man["base_commit"]))), str(work)], check=True)
         for pre in e["after"]:
             subprocess.run(["patch", "-p1", "-s", "-i", str(abl / pre)], cwd=work, check=True, capture_output=True)
         r = subprocess.run(["patch", "-p1", "--dry-run", "-i", str(abl / name)], cwd=work, capture_output=True, text=True)
-        assert r.returncode == 0, f"{name} does not apply to {man['base_commit']}: {r.stdout[-400:]}"
+        assert r.returncode == 0, f"{name} does not apply to {e.get('base', man['base_commit'])}: {r.stdout[-400:]}"
