@@ -795,9 +795,12 @@ __global__ __launch_bounds__(DENSIFY_THREADS, 4) void bev_densify_kernel(
                 const int j = j0 + (tid & (COLS - 1));
                 if (j >= crop) continue;
                 const int4 cx = cx_l[j + off];
-                // U rows at a time: all their gathers (the image out of the L2, the second image's pixel) are issued before the first is used --
+                // U rows at a time (SALVE_TILE_ROWS_IN_FLIGHT): all their gathers (the image out of the L2, the second image's pixel) are issued before the first is used --
                 // one row after the other the phase was a chain of dependent round trips, 112 per thread (+1.0 ms per 4096 renders)
-                constexpr int U = 4;
+#ifndef SALVE_TILE_ROWS_IN_FLIGHT
+#define SALVE_TILE_ROWS_IN_FLIGHT 8   // (r6, same-box A/B: 2 rows 14.62 ms, 4 rows 14.41, 8 rows 14.32 per 4096 renders)
+#endif
+                constexpr int U = SALVE_TILE_ROWS_IN_FLIGHT;
                 for (int i0 = tid / COLS; i0 < crop; i0 += RGROUPS * U) {
                     int4 cy[U];
                     uint32_t p00[U], p01[U], p10[U], p11[U], q[U];
