@@ -149,3 +149,23 @@ def test_tier_c_report_on_the_wide_sample(golden_dir):
         assert frac <= 0.12 and mean <= 2.5, meta
         worst = [max(worst[0], frac), max(worst[1], mean), max(worst[2], mx)]
     print(f"wide sample, worst case: {100 * worst[0]:.1f} % of the covered pixels, mean {worst[1]:.2f}, max {worst[2]} grey levels")
+
+
+def test_gemm_reference_shapes_are_the_forwards_three_by_three_convolutions():
+    """bench.py's GEMM reference is run at the shapes of the ResNet-50 forward's stride-1 3 x 3 convolutions as GEMMs at batch
+    4096 -- M = 4096 x output pixels, N = C_out, K = 9 C_in: taken here from the op program the verifier actually executes."""
+    import bench
+    from types import SimpleNamespace
+
+    import torch
+
+    from salve_amd.models import hip_resnet
+    from salve_amd.models.early_fusion import EarlyFusionCEResnet
+
+    torch.manual_seed(0)
+    model = EarlyFusionCEResnet(50, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"])).eval()
+    ops = hip_resnet.build_program(model.state_dict(), 50)[0]
+    want = {(4096 * int(o["Ho"]) * int(o["Wo"]), int(o["Cout"]), 9 * int(o["Cin"])) for o in ops
+            if o["op"] == hip_resnet.OP_CONV and o["KH"] == 3 and o["stride"] == 1 and o["Cin"] >= 128}
+    got = {(m, n, k) for name, m, n, k in bench.GEMM_SHAPES if not name.startswith("square")}
+    assert got == want, (sorted(got), sorted(want))
