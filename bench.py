@@ -233,13 +233,10 @@ def copy_probe(dev, gbytes: float = 4.0, iters: int = 20):
 
 
 def make_panos(n: int, pano_h: int, pano_w: int, scene: str):
-    """The synthetic panoramas of a run, generated by a few host threads (numpy releases the GIL; a 2048 x 1024 panorama takes 2 s)."""
-    from concurrent.futures import ThreadPoolExecutor
-
+    """The synthetic panoramas of a run (salve_amd.synthetic.make_panos: a few host threads)."""
     from salve_amd import synthetic
 
-    with ThreadPoolExecutor(max_workers=min(8, max(1, n))) as pool:
-        return list(pool.map(lambda i: synthetic.make_pano(i, pano_h, pano_w, scene=scene), range(n)))
+    return synthetic.make_panos(n, pano_h, pano_w, scene=scene)
 
 
 def config5_line(dev, hyps: int = 4096, panos: int = 16, steps: int = 3, warmup: int = 1):

@@ -199,6 +199,14 @@ def make_hypotheses(n: int, num_panos: int, seed: int = 0) -> HypothesisTable:
     )
 
 
+def make_panos(n: int, H: int = 512, W: int = 1024, scene: str = "box", threads: int = 8):
+    """[(rgb, depth)] of panoramas 0 .. n-1, generated by a few host threads (numpy releases the GIL; a 2048 x 1024 panorama takes 2 s)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=max(1, min(threads, n))) as pool:
+        return list(pool.map(lambda i: make_pano(i, H, W, scene=scene), range(n)))
+
+
 def trained_looking_batchnorm(model, seed: int = 0) -> None:
     """Give a freshly initialised verifier BatchNorm statistics that look like a trained network's, so that activations stay
     O(1) through the trunk.  (torchvision's initialisation -- weight 1, bias 0, mean 0, variance 1 -- is no normalisation

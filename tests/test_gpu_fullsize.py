@@ -239,15 +239,16 @@ def _oracle_config5_hypothesis(args):
 
 
 def test_config5_launch_shape_against_the_oracle():
-    """BASELINE config 5 at the shape `bench.py --pano-hw 1024x2048 --surfaces floor,ceiling --layers 152 --hyps 512 --panos 16
-    --chunk 512` launches: 512 hypotheses = 1024 renders per rasteriser launch over 2048 x 1024 panoramas (a splat grid of 16 k
-    workgroups), ResNet-152 with 12 input channels at batch 512 (where the 8-phase and the expand-chain kernels are selected).
-    8 sampled hypotheses end to end against the oracle: both posed BEV images bit for bit, logits absolute 1e-3."""
+    """BASELINE config 5 at the shape `bench.py` runs it (its `config5` object; `bench.py --pano-hw 1024x2048 --surfaces floor,ceiling
+    --layers 152 --panos 16`): 4096 hypotheses over 16 panoramas of 2048 x 1024, the launch size PICKED by the pipeline (pick_launch: the whole
+    shard = 8192 renders per rasteriser launch -- a splat grid of 131 k workgroups, the densify stage in costly-first order with its tile
+    phase writing the 16-channel samples), ResNet-152 with 12 input channels at batch 4096.  8 sampled hypotheses end to end against the
+    oracle: both posed BEV images bit for bit, logits absolute 1e-3."""
     from salve_amd.models.early_fusion import EarlyFusionCEResnet
     from salve_amd.pipeline import RenderVerifyPipeline
     from _helpers import randomise_bn
 
-    H, W, N, P = 1024, 2048, 512, 16
+    H, W, N, P = 1024, 2048, 4096, 16
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = EarlyFusionCEResnet(152, False, 2, SimpleNamespace(modalities=["ceiling_rgb_texture", "floor_rgb_texture"])).eval()
@@ -256,8 +257,9 @@ def test_config5_launch_shape_against_the_oracle():
     picked = np.random.default_rng(15).choice(N, 8, replace=False)
     with mp.get_context("spawn").Pool(8) as pool:
         pending = pool.map_async(_oracle_config5_hypothesis, [(hyp.i1[j], hyp.i2[j], hyp.R[j], hyp.t[j]) for j in picked], chunksize=1)
-        panos = [synthetic.make_pano(i, H, W) for i in range(P)]
-        pipe = RenderVerifyPipeline(model, dev, pano_hw=(H, W), chunk=N, overlap=False, streams=1)
+        panos = synthetic.make_panos(P, H, W)
+        pipe = RenderVerifyPipeline(model, dev, pano_hw=(H, W), chunk=None, overlap=False, streams=1, n_hypotheses=N)   # bench.py's config5_line
+        assert pipe.chunk == N, f"the pipeline was meant to pick the whole shard as one launch, picked {pipe.chunk}"
         pipe.load_panos(np.stack([p[0] for p in panos]), np.stack([p[1] for p in panos]))
         prepared = pipe.prepare(hyp)
         logits = pipe.score(prepared)
@@ -277,5 +279,5 @@ def test_config5_launch_shape_against_the_oracle():
         err = float(np.abs(got_logits[j] - logit_exp).max())
         worst = max(worst, err)
         assert err <= 1e-3, f"hypothesis {j}: logits {got_logits[j]} vs oracle {logit_exp}"
-    print(f"config 5 launch shape (512 hypotheses = 1024 renders per launch, ResNet-152 12-ch batch 512): 8 hypotheses, "
+    print(f"config 5 launch shape ({N} hypotheses = {2 * N} renders per launch, ResNet-152 12-ch batch {N}): 8 hypotheses, "
           f"BEV bit-exact, max |logit - oracle| {worst:.2e}")
