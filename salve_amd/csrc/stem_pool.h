@@ -31,8 +31,8 @@ constexpr int STEM_W = 224;            // the input width the kernel is written 
                                        // are immediates; other widths take the two-kernel path)
 
 struct StemArgs {
-    const uint16_t* x;      // [B, H, W, 8] fp16
-    const uint16_t* w;      // [64][7][8][8] fp16 (BatchNorm folded)
+    const uint16_t* x;      // [B, H, W, 8 G] fp16   (G = channel groups of 8: 1 for two images, 2 for four)
+    const uint16_t* w;      // [64][G][7][8][8] fp16 (BatchNorm folded): K ordered (group, kh, kw, channel in group)
     const float* bias;      // [64]
     uint16_t* y;            // [B, H / 4, W / 4, 64] fp16
     const uint16_t* zeros;
@@ -78,6 +78,14 @@ __device__ __forceinline__ void stem_lds_read8x4_strided(uint32_t addr, uint2 (&
 }
 #define STEM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   // (raw: __syncthreads() would drain the patch in flight)
 
+// G = 2 (r6; the 12-channel early fusion of two surfaces, input padded to 16 channels: BASELINE config 5): the SAME kernel run over the two channel
+// groups of 8 one after the other -- patch and weights of a group do not fit LDS beside those of the other (2 x (84 + 57) KB), so a strip
+// loads group 0's patch + weights, multiplies, loads group 1's into the same LDS, multiplies into the same accumulators, and the next strip's
+// group 0 streams in under the epilogue as before.  The host packs the stem's K in that order (group, kh, kw, channel in group) and the
+// two-kernel path walks it in the same order through its k table, so the pooled tensor is still bit-identical.  Before: the generic
+// convolution + max-pool, 7.4 + 1.7 ms per 4096 samples.  (The G = 1 instantiation is kept TEXTUALLY what it was: the kernel sits at 254
+// registers without scratch, and a scratch reload is a vmcnt load queued behind the next patch.)
+template <int G>
 __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) {
     constexpr int R = STEM_R, NPR = 4 * R + 7;                 // (2 R + 1 = 9 convolution rows per strip)
     constexpr int PATCH_E = NPR * (STEM_W + 6) * 8;        // uint16 elements
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) 
     const int frag_row_ = lane & 15, frag_q_ = lane >> 4;
 
     // ---- the weights, once (7 k-tiles of 64 rows x 128 bytes, source-side swizzle as in conv_igemm_kernel)
-    {
+    if constexpr (G == 1) {
         const int row_base = tid >> 3;
         const int chunk = (tid & 7) ^ ((row_base >> 1) & 7);
         const uint16_t* wsrc = p.w + (long long)row_base * 448 + chunk * 8;
@@ -110,6 +118,18 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) 
         for (int kt = 0; kt < 7; kt++)
             __builtin_amdgcn_global_load_lds((global_cptr)(wsrc + kt * 64), (lds_ptr)(wl + kt * 4096 + wave * 512), 16, 0, 0);
     }
+    // (G == 2) ... of channel group g, per strip and group
+    auto issue_weights = [&](int g) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));                           // (opaque: recomputed where it is used, not carried through the MFMA loops)
+        const int row_base = tl >> 3;
+        const int chunk = (tl & 7) ^ ((row_base >> 1) & 7);
+        const uint16_t* wsrc = p.w + (long long)row_base * (448 * G) + g * 448 + chunk * 8;
+#pragma unroll
+        for (int kt = 0; kt < 7; kt++)
+            __builtin_amdgcn_global_load_lds((global_cptr)(wsrc + kt * 64), (lds_ptr)(wl + kt * 4096 + wave * 512), 16, 0, 0);
+    };
+    if constexpr (G > 1) issue_weights(0);
     // ---- a strip's input patch: (4 R + 7) rows x (W + 6) columns x 16 bytes, zero padded, row-major
     auto issue_patch = [&](int b, int s) {
         const int iy_base = 4 * R * s - 5;                     // input row of patch row 0
@@ -128,10 +148,26 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) 
             }
         }
     };
+    auto issue_patch_g = [&](int b, int s, int g) {           // (G == 2) the same for channel group g of a 16-channel input
+        const int iy_base = 4 * R * s - 5;
+        int pc = PC;
+        asm volatile("" : "+s"(pc));
+        const int total = NPR * pc;
+        const uint16_t* ximg = p.x + (long long)b * H * W * (8 * G) + 8 * g;
+        for (int i0 = 0; i0 < total; i0 += STEM_THREADS) {
+            const int i = i0 + tid;
+            if (i < total) {
+                const int prow = i / pc, pcol = i - prow * pc;
+                const int iy = iy_base + prow, ix = pcol - 3;
+                const uint16_t* src = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? ximg + ((long long)iy * W + ix) * (8 * G) : p.zeros;
+                __builtin_amdgcn_global_load_lds((global_cptr)src, (lds_ptr)(patch + (i0 + wave * 64) * 8), 16, 0, 0);
+            }
+        }
+    };
     // (image, strip) of the workgroup's current strip: 32-bit counters -- a 64-bit division per strip lives in vector registers
     int b = __builtin_amdgcn_readfirstlane((int)(st_lo / strips)), s = __builtin_amdgcn_readfirstlane((int)(st_lo % strips));
     const int n_mine = __builtin_amdgcn_readfirstlane((int)(st_hi - st_lo));
-    issue_patch(b, s);
+    if constexpr (G == 1) issue_patch(b, s); else issue_patch_g(b, s, 0);
 
     // ---- who computes what: wave w < tiles_x the rows 0 .. R-1, R+1 .. 2R of column w, wave 7 row R of every column
     const bool row_wave = wave == 7, col_wave = wave < tiles_x && wave < 7;
@@ -158,26 +194,60 @@ __global__ __launch_bounds__(STEM_THREADS, 2) void stem_pool_kernel(StemArgs p) 
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kh = 0; kh < 7; kh++) {
+        if constexpr (G == 1) {
+            for (int kh = 0; kh < 7; kh++) {
+    #pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    act8 af[8], bfr[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        bfr[j] = *reinterpret_cast<const act8*>(wl + kh * 4096 + (j * 16 + frag_row_) * 64 + (((h * 4 + frag_q_) ^ bsw) * 8));
+    #pragma unroll
+                    for (int i = 0; i < 8; i++) af[i] = *reinterpret_cast<const act8*>(patch + abase[i] + (kh * PC + 4 * h) * 8);
+    #pragma unroll
+                    for (int i = 0; i < 8; i++)
+    #pragma unroll
+                        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
+            // two channel groups, ONE copy of the loop: the second group's patch and weights go into the LDS the first was read from and are
+            // multiplied into the same accumulators
+#pragma unroll 1
+            for (int g = 0; g < G; g++) {
+                if (g > 0) {
+                    __syncthreads();
+                    issue_patch_g(b, s, g);
+                    issue_weights(g);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+                for (int kh = 0; kh < 7; kh++) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                act8 af[8], bfr[4];
+                    for (int h = 0; h < 2; h++) {
+                        act8 af[8], bfr[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    bfr[j] = *reinterpret_cast<const act8*>(wl + kh * 4096 + (j * 16 + frag_row_) * 64 + (((h * 4 + frag_q_) ^ bsw) * 8));
+                        for (int j = 0; j < 4; j++)
+                            bfr[j] = *reinterpret_cast<const act8*>(wl + kh * 4096 + (j * 16 + frag_row_) * 64 + (((h * 4 + frag_q_) ^ bsw) * 8));
 #pragma unroll
-                for (int i = 0; i < 8; i++) af[i] = *reinterpret_cast<const act8*>(patch + abase[i] + (kh * PC + 4 * h) * 8);
+                        for (int i = 0; i < 8; i++) af[i] = *reinterpret_cast<const act8*>(patch + abase[i] + (kh * PC + 4 * h) * 8);
 #pragma unroll
-                for (int i = 0; i < 8; i++)
+                        for (int i = 0; i < 8; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+                }
             }
         }
         __syncthreads();                                       // everyone is done reading the patch
         float4 bias[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) bias[j] = lds_read_f4(bias_s + j * 16 + 4 * frag_q_);
-        if (k + 1 < n_mine) issue_patch(b_next, s_next);       // ... so the next one streams in under the rest of this strip
+        if constexpr (G == 1) {
+            if (k + 1 < n_mine) issue_patch(b_next, s_next);   // ... so the next one streams in under the rest of this strip
+        } else {
+            if (k + 1 < n_mine) { issue_patch_g(b_next, s_next, 0); issue_weights(0); }
+        }
         {
             // (the LDS addresses of the hand-over are recomputed per strip from an opaque copy of the lane's coordinates: hoisted out
             //  of the strip loop they cost 77 spilled registers, reloaded inside the MFMA loop)

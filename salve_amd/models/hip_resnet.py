@@ -57,11 +57,20 @@ class _Builder:
         wp[:, :, :KW, :Cin] = w.permute(0, 2, 3, 1)
         K = KH * KWp * Cinp
         assert K % 64 == 0 and Cout % 64 == 0, (K, Cout)
-        bits = wp.reshape(Cout, K).to(torch.float16).view(torch.int16).numpy().copy()
         q = np.arange(K // 8)
-        c8 = q % (Cinp // 8)
-        kw = (q // (Cinp // 8)) % KWp
-        kh = q // ((Cinp // 8) * KWp)
+        if KH == 7 and KWp == 8 and Cinp == 16:
+            # the 16-channel stem (two surfaces: 12 channels): K ordered (group of 8 channels, kh, kw, channel in group), so that a k-tile of 64 is one
+            # kernel row of ONE channel group -- the order in which the fused stem kernel (stem_pool.h, G = 2) walks its two groups; the implicit-GEMM
+            # kernel follows the k table, so the two-kernel path multiplies in the same order (bit-identical pooled tensors)
+            wp = wp.reshape(Cout, KH, KWp, 2, 8).permute(0, 3, 1, 2, 4).contiguous()
+            c8 = q // (KH * KWp)
+            kh = (q % (KH * KWp)) // KWp
+            kw = q % KWp
+        else:
+            c8 = q % (Cinp // 8)
+            kw = (q // (Cinp // 8)) % KWp
+            kh = q // ((Cinp // 8) * KWp)
+        bits = wp.reshape(Cout, K).to(torch.float16).view(torch.int16).numpy().copy()
         tab = ((kh & 0xFF) | ((kw & 0xFF) << 8) | ((c8 * 8) << 16)).astype(np.int32)
         Ho = (Hi + 2 * pad - KH) // stride + 1
         Wo = (Wi + 2 * pad - KW) // stride + 1

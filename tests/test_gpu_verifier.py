@@ -435,16 +435,20 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(layer
     assert torch.equal(outs["2a"], outs["0"]) and torch.equal(outs["2na"], outs["0"]), "store-all form differs"
 
 
-def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool():
+@pytest.mark.parametrize("modalities,cin,batch", [(["floor_rgb_texture"], 8, 3), (["ceiling_rgb_texture", "floor_rgb_texture"], 16, 3),
+                                                  (["ceiling_rgb_texture", "floor_rgb_texture"], 16, 37)])
+def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool(modalities, cin, batch):
     """stem_pool_kernel (7x7 / 2 convolution + BatchNorm + ReLU + 3x3 / 2 max-pool in one launch, input patch in LDS) rounds
     every convolution output to fp16 before the max, exactly as the two-kernel path stores it, and accumulates in the same k
-    order: the logits must agree bit for bit -- image borders (zero padding, pooling windows cut by the edge) included."""
+    order: the logits must agree bit for bit -- image borders (zero padding, pooling windows cut by the edge) included.  16 input
+    channels (two surfaces, r6): the kernel walks two channel groups of 8 through the same LDS, the stem's K is packed group-major and the
+    two-kernel path follows it through its k table; 37 samples give every persistent workgroup several strips."""
     torch.manual_seed(8)
-    model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=["floor_rgb_texture"]))
+    model = EarlyFusionCEResnet(18, False, 2, SimpleNamespace(modalities=modalities))
     randomise_bn(model, seed=8)
     model.eval()
-    x = torch.randn(3, 224, 224, 8).to(torch.float16).to(DEV)
-    x[..., 6:] = 0
+    x = torch.randn(batch, 224, 224, cin).to(torch.float16).to(DEV)
+    x[..., (6 if cin == 8 else 12):] = 0
     outs = []
     for flags in (0, _lib.RESNET_NO_STEM_FUSE):
         eng = hip_resnet.HipResNet(model.state_dict(), 18, torch.device(DEV), flags=flags)
