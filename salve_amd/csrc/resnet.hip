@@ -1096,15 +1096,15 @@ void* salve_resnet_create(int32_t num_layers, int32_t in_channels, const salve_r
         for (size_t i = 0; enable && i + 1 < h->ops.size(); i++) {
             const salve_resnet_op_t &a = h->ops[i], &b = h->ops[i + 1];
             if (a.op != SALVE_OP_CONV || b.op != SALVE_OP_MAXPOOL) continue;
-            bool k_order = a.Cin == 8;   // 16 input channels: the fused kernel needs K ordered (group of 8 channels, kh, kw, channel): read it off the k table
-            if (a.Cin == 16 && a.KH == 7 && a.KW == 8 && (size_t)a.ktab_off + 2 * 7 * 8 <= ktab_entries) {
+            bool k_order = a.Cin == 8;   // 16 / 24 input channels: the fused kernel needs K ordered (group of 8 channels, kh, kw, channel): read it off the k table
+            if ((a.Cin == 16 || a.Cin == 24) && a.KH == 7 && a.KW == 8 && (size_t)a.ktab_off + (size_t)(a.Cin / 8) * 7 * 8 <= ktab_entries) {
                 k_order = true;
-                for (int q = 0; q < 2 * 7 * 8 && k_order; q++) {
+                for (int q = 0; q < (a.Cin / 8) * 7 * 8 && k_order; q++) {
                     const int g = q / 56, kh = (q % 56) / 8, kw = q % 8;
                     k_order = ktab[a.ktab_off + q] == ((kh & 0xFF) | ((kw & 0xFF) << 8) | ((8 * g) << 16));
                 }
             }
-            const bool shape = a.KH == 7 && a.KW == 8 && a.stride == 2 && a.pad == 3 && (a.Cin == 8 || a.Cin == 16) && k_order && a.Cout == 64 && a.relu &&
+            const bool shape = a.KH == 7 && a.KW == 8 && a.stride == 2 && a.pad == 3 && (a.Cin == 8 || a.Cin == 16 || a.Cin == 24) && k_order && a.Cout == 64 && a.relu &&
                                a.res_buf == SALVE_NO_BUF && a.in2_buf == SALVE_NO_BUF && b.in_buf == a.out_buf && b.Cin == 64 &&
                                a.Hi % 4 == 0 && a.Wi % 4 == 0 && a.Wi == STEM_W && (a.Hi / 4) % STEM_R == 0 &&
                                a.Ho == a.Hi / 2 && a.Wo == a.Wi / 2 && b.Ho == a.Hi / 4 && b.Wo == a.Wi / 4;
@@ -1288,7 +1288,8 @@ int salve_resnet_forward(void* handle, const void* input, int32_t batch, float* 
             a.B = batch; a.H = o.Hi; a.W = o.Wi; a.status = status;
             const long long strips = (long long)batch * ((o.Hi / 4) / STEM_R);
             const unsigned grid = (unsigned)(strips < h->n_cus ? strips : h->n_cus);   // persistent: one workgroup per CU, a contiguous range of strips each
-            if (o.Cin == 16) hipLaunchKernelGGL(stem_pool_kernel<2>, dim3(grid), dim3(STEM_THREADS), 0, s, a);
+            if (o.Cin == 24) hipLaunchKernelGGL(stem_pool_kernel<3>, dim3(grid), dim3(STEM_THREADS), 0, s, a);
+            else if (o.Cin == 16) hipLaunchKernelGGL(stem_pool_kernel<2>, dim3(grid), dim3(STEM_THREADS), 0, s, a);
             else hipLaunchKernelGGL(stem_pool_kernel<1>, dim3(grid), dim3(STEM_THREADS), 0, s, a);
             SALVE_HIP_CHECK(hipGetLastError());
             oi += 1;

@@ -78,7 +78,7 @@ __device__ __forceinline__ void stem_lds_read8x4_strided(uint32_t addr, uint2 (&
 }
 #define STEM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   // (raw: __syncthreads() would drain the patch in flight)
 
-// G = 2 (r6; the 12-channel early fusion of two surfaces, input padded to 16 channels: BASELINE config 5): the SAME kernel run over the two channel
+// G = 2 / 3 (r6; the 12-channel early fusion of two surfaces, input padded to 16 channels: BASELINE config 5; 18 -> 24 with the layout modality): the SAME kernel run over the channel
 // groups of 8 one after the other -- patch and weights of a group do not fit LDS beside those of the other (2 x (84 + 57) KB), so a strip
 // loads group 0's patch + weights, multiplies, loads group 1's into the same LDS, multiplies into the same accumulators, and the next strip's
 // group 0 streams in under the epilogue as before.  The host packs the stem's K in that order (group, kh, kw, channel in group) and the

@@ -58,11 +58,11 @@ class _Builder:
         K = KH * KWp * Cinp
         assert K % 64 == 0 and Cout % 64 == 0, (K, Cout)
         q = np.arange(K // 8)
-        if KH == 7 and KWp == 8 and Cinp == 16:
-            # the 16-channel stem (two surfaces: 12 channels): K ordered (group of 8 channels, kh, kw, channel in group), so that a k-tile of 64 is one
-            # kernel row of ONE channel group -- the order in which the fused stem kernel (stem_pool.h, G = 2) walks its two groups; the implicit-GEMM
+        if KH == 7 and KWp == 8 and Cinp in (16, 24):
+            # the 16- / 24-channel stem (two surfaces: 12 channels; + layout: 18): K ordered (group of 8 channels, kh, kw, channel in group), so that a k-tile of 64 is one
+            # kernel row of ONE channel group -- the order in which the fused stem kernel (stem_pool.h, G = 2 / 3) walks its channel groups; the implicit-GEMM
             # kernel follows the k table, so the two-kernel path multiplies in the same order (bit-identical pooled tensors)
-            wp = wp.reshape(Cout, KH, KWp, 2, 8).permute(0, 3, 1, 2, 4).contiguous()
+            wp = wp.reshape(Cout, KH, KWp, Cinp // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
             c8 = q // (KH * KWp)
             kh = (q % (KH * KWp)) // KWp
             kw = q % KWp

@@ -436,7 +436,8 @@ def test_expand_chain_kernel_is_bit_identical_to_the_implicit_gemm_kernels(layer
 
 
 @pytest.mark.parametrize("modalities,cin,batch", [(["floor_rgb_texture"], 8, 3), (["ceiling_rgb_texture", "floor_rgb_texture"], 16, 3),
-                                                  (["ceiling_rgb_texture", "floor_rgb_texture"], 16, 37)])
+                                                  (["ceiling_rgb_texture", "floor_rgb_texture"], 16, 37),
+                                                  (["ceiling_rgb_texture", "floor_rgb_texture", "layout"], 24, 5)])
 def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool(modalities, cin, batch):
     """stem_pool_kernel (7x7 / 2 convolution + BatchNorm + ReLU + 3x3 / 2 max-pool in one launch, input patch in LDS) rounds
     every convolution output to fp16 before the max, exactly as the two-kernel path stores it, and accumulates in the same k
@@ -448,7 +449,7 @@ def test_fused_stem_is_bit_identical_to_convolution_plus_maxpool(modalities, cin
     randomise_bn(model, seed=8)
     model.eval()
     x = torch.randn(batch, 224, 224, cin).to(torch.float16).to(DEV)
-    x[..., (6 if cin == 8 else 12):] = 0
+    x[..., {8: 6, 16: 12, 24: 18}[cin]:] = 0
     outs = []
     for flags in (0, _lib.RESNET_NO_STEM_FUSE):
         eng = hip_resnet.HipResNet(model.state_dict(), 18, torch.device(DEV), flags=flags)
