@@ -1161,7 +1161,8 @@ size_t salve_bev_workspace_bytes(const salve_bev_config_t* cfg, int32_t n) {
 size_t salve_bev_pano_index_bytes(const salve_bev_config_t* cfg, int32_t n_panos) {
     DevCfg d;
     if (n_panos <= 0 || !make_devcfg(cfg, &d)) return 0;
-    return (size_t)n_panos * 2 * (pano_grid(d).entries() * sizeof(float4) + 2 * sizeof(int32_t));
+    // boxes [2 P][entries] | range_lo [2 P] | range_hi [2 P] | (r6) group boxes [2 P][groups]   (every part a multiple of 16 bytes)
+    return (size_t)n_panos * 2 * (pano_grid(d).entries() * sizeof(float4) + 2 * sizeof(int32_t) + (size_t)pano_grid(d).groups() * sizeof(float4));
 }
 
 static const int* index_ranges(const DevCfg& d, const void* pano_index, int n_panos) {
@@ -1187,6 +1188,10 @@ int salve_bev_pano_index_build(const salve_bev_config_t* cfg, const uint16_t* pa
     if ((waves + 3) / 4 > 0x7FFFFFFFll) { salve_fail("too many panoramas for one index launch"); return SALVE_ERR_BAD_ARG; }
     hipLaunchKernelGGL(bev_pano_index_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, d, pg, pano_depth, sphere,
                        reinterpret_cast<float4*>(pano_index), ranges, ranges + 2 * n_panos, n_panos);
+    SALVE_HIP_CHECK(hipGetLastError());
+    const long long n_gb = (long long)pg.groups() * 2 * n_panos;   // second level: the union box of every group of 64 blocks
+    hipLaunchKernelGGL(bev_pano_group_kernel, dim3((unsigned)((n_gb + 255) / 256)), dim3(256), 0, s, pg, reinterpret_cast<const float4*>(pano_index),
+                       reinterpret_cast<float4*>(ranges + 4 * n_panos), 2 * n_panos);
     SALVE_HIP_CHECK(hipGetLastError());
     return SALVE_OK;
 }

@@ -105,11 +105,42 @@ __global__ __launch_bounds__(256) void bev_pano_index_kernel(DevCfg c, PanoGrid 
     }
 }
 
+// (r6) Second level of the index: the union box of every GROUP of 64 blocks.  A tile's workgroup tests the group boxes first -- all of them in one
+// pass, a box per thread -- and its wavefronts then visit only the groups that can reach the tile; before, every wavefront walked the whole
+// range of groups that hold points, one dependent LDS atomic + 1 KB box load + ballot per group (2048 x 1024 panoramas: 176 visits per tile and
+// render, 20 % of the kernel's time; a tile is reached by a sixth of them).
+__global__ __launch_bounds__(256) void bev_pano_group_kernel(PanoGrid pg, const float4* __restrict__ boxes, float4* __restrict__ gboxes, int n_ps) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long groups = pg.groups();
+    if (i >= groups * n_ps) return;
+    const float4* b = boxes + (size_t)(i / groups) * pg.entries() + (size_t)(i % groups) * 64;
+    float xmin = 1e30f, ymin = 1e30f, xmax = -1e30f, ymax = -1e30f;
+    for (int j = 0; j < 64; j++) {
+        const float4 v = b[j];
+        if (v.x <= v.z) { xmin = fminf(xmin, v.x); ymin = fminf(ymin, v.y); xmax = fmaxf(xmax, v.z); ymax = fmaxf(ymax, v.w); }
+    }
+    gboxes[i] = make_float4(xmin, ymin, xmax, ymax);
+}
+
+// can the box (pre-rotated frame) reach the tile [wx0, wx1] x [wy0, wy1] (posed frame) under the pose?  float32, conservative: centre + |R| half-extents
+// + the rounding slack of the test itself; an empty box (x > z) reaches nothing
+__device__ __forceinline__ bool splat_reaches(const float4 bb, float fR00, float fR01, float fR10, float fR11, float ftx, float fty, float wx0,
+                                              float wx1, float wy0, float wy1) {
+    const float cx = 0.5f * (bb.x + bb.z), cy = 0.5f * (bb.y + bb.w), hx = 0.5f * (bb.z - bb.x), hy = 0.5f * (bb.w - bb.y);
+    const float px = fR00 * cx + fR01 * cy + ftx, py = fR10 * cx + fR11 * cy + fty;
+    const float qx = fabsf(fR00) * hx + fabsf(fR01) * hy, qy = fabsf(fR10) * hx + fabsf(fR11) * hy;
+    const float slack = 1e-5f * (fabsf(cx) + fabsf(cy) + hx + hy + fabsf(ftx) + fabsf(fty));
+    return bb.x <= bb.z && px + qx + slack >= wx0 && px - qx - slack <= wx1 && py + qy + slack >= wy0 && py - qy - slack <= wy1;
+}
+
 // LDS of the splat / emit kernels: key tile, the tile's bitmap words, two counters.
+constexpr int GLIST_CAP = 1024;   // groups of 64 blocks a tile's pre-cull can list (2048 x 1024 panoramas: 352 groups per surface)
 struct SplatLds {
     uint32_t tile[TILE_H * TILE_LD];
     uint32_t bm[2][TILE_H][TILE_WORDS];
     int next_group, in_window;
+    int n_list;                 // (r6) groups whose union box can reach this tile ...
+    int glist[GLIST_CAP];       // ... listed by the pre-cull, in any order (winners are maxima: order-independent)
 };
 
 // Emission of a finished key tile: sparse-image tile + bitmap words (layout of the bitmaps of one render:
@@ -206,7 +237,7 @@ __global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_
 
     static_assert((TILE_H * TILE_LD) % 4 == 0, "the key tile is zeroed in 16-byte pieces, the bitmap words behind it are read in such");
     for (int i = tid; i < TILE_H * TILE_LD / 4; i += SPLAT_THREADS) reinterpret_cast<uint4*>(s.tile)[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0) { s.next_group = 0; s.in_window = 0; }
+    if (tid == 0) { s.next_group = 0; s.in_window = 0; s.n_list = 0; }
 
     // The tile in the posed frame: pixel index rint((x + tx) * scale) in [tx0, tx0 + tw) <=> x in [(tx0 - .5) / scale - tx,
     // (tx0 + tw - .5) / scale - tx]; border tiles reach to the window's edge (they own the points whose index clamps to them),
@@ -236,23 +267,32 @@ __global__ __launch_bounds__(SPLAT_THREADS, SPLAT_THREADS / 128) void bev_splat_
     const double ptx = (double)(h.t[0] * 1.5f), pty = (double)(h.t[1] * 1.5f);   // float32 product, then widened (:451)
     const uint16_t* dpano = depth + (bad_row ? (size_t)0 : (size_t)h.pano_idx * c.pano_h * c.pano_w);
     int my_in_window = 0;
+#define SPLAT_REACHES(BB) splat_reaches((BB), fR00, fR01, fR10, fR11, ftx, fty, wx0, wx1, wy0, wy1)
     __syncthreads();
+    // ---- pre-cull (r6): the groups whose UNION box reaches the tile, a group per thread, listed in LDS (bev_pano_group_kernel)
+    const bool listed = g_hi - g_lo <= GLIST_CAP;
+    if (listed) {
+        const float4* gb = reinterpret_cast<const float4*>(range_lo + 4 * n_panos) + (size_t)ps * pg.groups();
+        for (int i = g_lo + tid; i < g_hi; i += SPLAT_THREADS)
+        {
+            const float4 gbb = gb[i];
+            if (SPLAT_REACHES(gbb)) s.glist[atomicAdd(&s.n_list, 1)] = i;
+        }
+        __syncthreads();
+    }
+    const int n_visit = listed ? s.n_list : g_hi - g_lo;
 
     for (;;) {
         // a wavefront takes one group of 64 blocks at a time (dynamic: the groups that reach a tile are few and uneven)
         int g = 0;
-        if (lane == 0) g = atomicAdd(&s.next_group, 1);
-        g = __shfl(g, 0) + g_lo;
-        if (g >= g_hi) break;
-        const float4 bb = bx[(size_t)g * 64 + lane];
-        bool hit = bb.x <= bb.z;
-        {
-            const float cx = 0.5f * (bb.x + bb.z), cy = 0.5f * (bb.y + bb.w), hx = 0.5f * (bb.z - bb.x), hy = 0.5f * (bb.w - bb.y);
-            const float px = fR00 * cx + fR01 * cy + ftx, py = fR10 * cx + fR11 * cy + fty;
-            const float qx = fabsf(fR00) * hx + fabsf(fR01) * hy, qy = fabsf(fR10) * hx + fabsf(fR11) * hy;
-            const float slack = 1e-5f * (fabsf(cx) + fabsf(cy) + hx + hy + fabsf(ftx) + fabsf(fty));   // float32 rounding of the test itself
-            hit = hit && px + qx + slack >= wx0 && px - qx - slack <= wx1 && py + qy + slack >= wy0 && py - qy - slack <= wy1;
+        if (lane == 0) {
+            g = atomicAdd(&s.next_group, 1);
+            g = g < n_visit ? (listed ? s.glist[g] : g_lo + g) : -1;
         }
+        g = __shfl(g, 0);
+        if (g < 0) break;
+        const float4 bb = bx[(size_t)g * 64 + lane];
+        const bool hit = SPLAT_REACHES(bb);
         unsigned long long m = __ballot(hit);
         if (m == 0ull) continue;
         const int br = g / pg.gpr, gc = g - br * pg.gpr;
