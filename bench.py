@@ -543,6 +543,27 @@ def main() -> None:
                 out["roofline_verifier"].update({"power_w": probe["power_w"], "power_cap_w": probe["power_cap_w"], "sclk_mhz": probe["sclk_mhz"], "power_samples": probe["samples"],
                                                  "peak_at_sclk": round(MFMA_PEAK_TFLOPS * probe["sclk_mhz"] / 2400.0, 1),
                                                  "frac_at_sclk": round(tflops / (MFMA_PEAK_TFLOPS * probe["sclk_mhz"] / 2400.0), 5)})
+        if world == 1 and not args.no_calibration:
+            # the densify stage WITHOUT its tile phase (salve_bev_densify instead of salve_bev_densify_tiles), outside the timed region: since round 6 the
+            # verifier tiles are written by the densify kernel's last phase, so `densify_ms` above carries work SURVEY 8d's bytes do not count --
+            # this is the stage as rounds 1-5 timed it, for a like-for-like `frac`
+            try:
+                S_ = len(pipe.surfaces)
+                evs = []
+                for _ in range(4):
+                    pipe._scatter_chunk(prepared, 0, full_n, 0, 0)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    pipe.ras.densify(full_n * S_, pipe.bevs[0])
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                d_only = float(np.mean([a.elapsed_time(b) for a, b in evs[1:]]))
+                out["roofline"].update({"densify_without_tile_phase_ms": round(d_only, 3),
+                                        "frac_without_tile_phase": round(renders * bpr / ((scat_ms + d_only) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)})
+            except Exception as ex:
+                out["roofline"]["densify_without_tile_phase_ms"] = None
+                out["roofline"]["densify_without_tile_phase_error"] = str(ex)[:200]
         if world == 1 and not (args.no_calibration and args.no_config5):
             # everything below needs the memory, not the pipeline: release the main workload's buffers
             del pipe, prepared, logits, allg, table
