@@ -55,7 +55,17 @@ assert st == 0
 torch.cuda.synchronize()
 hard = stats[:, 6].cpu().numpy().astype(np.float64)
 del scratch
-feat = {"HARD sites (true count after E1)": hard, "sites": sites, "sites with a 4-neighbour missing": b1, "sites with >= 2 4-neighbours missing": b2, "sites with >= 5 of 8 neighbours missing": b3}
+# (r6) a PRIOR that needs no split launch: the hard-site count of the render's PANORAMA at identity pose (known once per panorama set, from load_panos'
+# identity renders) -- does a panorama's count predict its posed renders'?
+from salve_amd.rasteriser import pack_hypotheses, SURFACES
+ih = pack_hypotheses(np.arange(P), np.zeros(P, dtype=np.int64), np.tile(np.eye(2, dtype=np.float32), (P, 1, 1)), np.zeros((P, 2), np.float32), np.zeros(P))
+_, dbg = pipe.ras.render(pipe.pano_rgb, pipe.pano_depth, pipe.ras.upload_hypotheses(ih), P, debug=True)
+torch.cuda.synchronize()
+hard_ident = dbg.stats[:, 6].cpu().numpy().astype(np.float64)
+prior = hard_ident[np.asarray(table.i1)][np.argsort(prep["rank"])]      # render order, like the other features (converted below)
+print("identity hard sites per panorama: min %d median %d max %d; correlation with the posed renders' true count: %.2f" %
+      (hard_ident.min(), np.median(hard_ident), hard_ident.max(), np.corrcoef(prior, hard)[0, 1]))
+feat = {"HARD sites (true count after E1)": hard, "panorama's identity hard sites (prior)": prior, "sites": sites, "sites with a 4-neighbour missing": b1, "sites with >= 2 4-neighbours missing": b2, "sites with >= 5 of 8 neighbours missing": b3}
 feat = {k: v[prep["rank"]] for k, v in feat.items()}   # render order -> hypothesis order
 for k, v in feat.items():
     print(f"{k}: min {v.min():.0f} median {np.median(v):.0f} max {v.max():.0f}")
@@ -65,6 +75,8 @@ for k, v in feat.items():
     orders[k + ", descending"] = np.argsort(-v, kind="stable")
 for wgt in (0.01, 0.03):
     orders[f"hard + {wgt} sites, descending"] = np.argsort(-(feat["HARD sites (true count after E1)"] + wgt * feat["sites"]), kind="stable")
+for wgt in (2.0, 5.0, 10.0):
+    orders[f"b2 + {wgt} x panorama prior, descending"] = np.argsort(-(feat["sites with >= 2 4-neighbours missing"] + wgt * feat["panorama's identity hard sites (prior)"]), kind="stable")
 orders["b2 + 0.05 sites, descending"] = np.argsort(-(feat["sites with >= 2 4-neighbours missing"] + 0.05 * feat["sites"]), kind="stable")
 for wgt in (2, 4, 8):
     orders[f"b1 + {wgt} b3, descending"] = np.argsort(-(feat["sites with a 4-neighbour missing"] + wgt * feat["sites with >= 5 of 8 neighbours missing"]), kind="stable")
